@@ -1,0 +1,313 @@
+"""Pins the CPU oracle (oracle/egr_oracle.cpp) without the reference binary (which cannot be built here):
+golden vectors from the reference's importable helper, integer-exact RNG, and hand-derived scenes
+(SURVEY.md §8c items 1-2). CPU only."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MAX_ALPHA = float(np.float32(0.9999))  # flags.h:7 is a float literal
+
+
+# ------------------------------------------------------------------ RNG (utils/random.h:34-62)
+def _tea4_py(v0, v1):
+    M = 0xFFFFFFFF
+    s0 = 0
+    for _ in range(4):
+        s0 = (s0 + 0x9E3779B9) & M
+        v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C & M) ^ ((v1 + s0) & M) ^ (((v1 >> 5) + 0xC8013EA4) & M))) & M
+        v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D & M) ^ ((v0 + s0) & M) ^ (((v0 >> 5) + 0x7E95761E) & M))) & M
+    return v0
+
+
+def test_tea4_matches_independent_python(orc):
+    for a, b in [(0, 0), (0, 1), (1, 1), (12345, 678), (2073599, 30000), (0xFFFFFFFF, 0xFFFFFFFF)]:
+        assert orc.tea4(a, b) == _tea4_py(a, b)
+
+
+def test_lcg_sequence_is_numerical_recipes_lcg(orc):
+    seq, state = orc.lcg_sequence(0, 4)
+    s, exp = 0, []
+    for _ in range(4):
+        s = (1664525 * s + 1013904223) & 0xFFFFFFFF
+        exp.append(s & 0xFFFFFF)
+    assert seq == exp and state == s
+    assert seq[0] == 1013904223 & 0xFFFFFF  # first draw from seed 0
+
+
+# ------------------------------------------------------------------ camera (core/camera.h:17-36)
+def test_primary_rays_match_reference_helper_golden(orc):
+    """Golden vectors were produced by importing the reference's compute_primary_ray_directions
+    (tests/golden/make_reference_vectors.py)."""
+    z = np.load(os.path.join(GOLD, "reference_primary_rays.npz"))
+    for i in range(4):
+        h, w = z[f"case{i}_hw"]
+        o = orc.Oracle(int(w), int(h), double=True)
+        o.set_camera(np.zeros(3), z[f"case{i}_c2w"], float(z[f"case{i}_fov"]))
+        d = o.primary_rays(jitter=False)
+        assert np.abs(d - z[f"case{i}_dirs"]).max() < 1e-12
+        o32 = orc.Oracle(int(w), int(h), double=False)
+        o32.set_camera(np.zeros(3), z[f"case{i}_c2w"], float(z[f"case{i}_fov"]))
+        assert np.abs(o32.primary_rays(jitter=False) - z[f"case{i}_dirs"]).max() < 2e-6
+
+
+def test_jitter_draw_order_and_range(orc):
+    o = orc.Oracle(8, 6, double=True)
+    o.set_camera(np.zeros(3), np.eye(3), 0.8)
+    dj = o.primary_rays(jitter=True, total_num_calls=7)
+    d0 = o.primary_rays(jitter=False)
+    # reconstruct pixel (3,2): seed=tea4(pixel_id, calls); jitter.x is the FIRST draw, jitter.y the second
+    seq, _ = orc.lcg_sequence(orc.tea4(2 * 8 + 3, 7), 2)
+    jx, jy = seq[0] / 2 ** 24 - 0.5, seq[1] / 2 ** 24 - 0.5
+    view = math.tan(0.4)
+    y = view * (1 - 2 * (2 + jy + 0.5) / 6)
+    x = 8 / 6 * view * (2 * (3 + jx + 0.5) / 8 - 1)
+    v = np.array([x, y, -1.0])
+    assert np.abs(dj[2, 3] - v / np.linalg.norm(v)).max() < 1e-6
+    assert np.abs(dj - d0).max() < 0.2 and np.abs(dj - d0).max() > 0
+
+
+# ------------------------------------------------------------------ single Gaussian
+def _one_gaussian(orc, syn, s=0.3, o_act=0.1, b=0.2, t=3.0, rgb=(0.3, 0.6, 0.9), double=True, W=1, H=1, **cfg):
+    """Isotropic Gaussian of scale s at distance t on the +x axis, offset sideways by b; 1x1 image so the
+    only ray is the optical axis."""
+    cam = syn.plus_x_camera()
+    oc = orc.Oracle(W, H, double=double, use_bvh=False)
+    oc.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+    oc.set_config(jitter_primary_rays=0, num_bounces=0, **cfg)
+    g = dict(rgb=np.array([rgb]), normal=np.array([[-1.0, 0, 0]]), f0=np.array([[0.04, 0.05, 0.06]]),
+             roughness=np.array([[0.25]]), opacity=np.array([[math.log(o_act / (1 - o_act))]]),
+             scale=np.full((1, 3), math.log(s)), mean=np.array([[t, b, 0.0]]), rotation=np.array([[1.0, 0, 0, 0]]))
+    oc.set_gaussians(g)
+    oc.update_bvh()
+    return oc, g
+
+
+def test_single_gaussian_analytic(orc, syn):
+    s, o_act, b, t = 0.3, 0.1, 0.2, 3.0
+    oc, g = _one_gaussian(orc, syn, s, o_act, b, t)
+    out = oc.raytrace(False)
+    r2 = (b / s) ** 2
+    alpha = MAX_ALPHA * o_act * math.exp(-(r2 ** 3) / 6.0)
+    np.testing.assert_allclose(out["output_transmittance"][0, 0, 0, 0], 1 - alpha, rtol=1e-6)
+    np.testing.assert_allclose(out["output_total_transmittance"][0, 0, 0, 0], 1 - alpha, rtol=1e-6)
+    np.testing.assert_allclose(out["output_rgb"][0, 0, 0], np.array([0.3, 0.6, 0.9]) * alpha, rtol=1e-6)
+    np.testing.assert_allclose(out["output_depth"][0, 0, 0, 0], t * alpha, rtol=1e-6)
+    np.testing.assert_allclose(out["output_normal"][0, 0, 0], np.array([-1.0, 0, 0]) * alpha, rtol=1e-6)
+    np.testing.assert_allclose(out["output_roughness"][0, 0, 0, 0], 0.25 * alpha, rtol=1e-6)
+    assert out["num_traversed"][0, 0] == 1 and out["num_accumulated"][0, 0] == 1
+    # |N| < 0.7 -> path ends at step 0 but the step is counted (shaders.cu:105,123)
+    assert out["effective_steps"][0, 0] == 1
+
+
+def test_clip_radius_is_s_times_sigma(orc, syn):
+    s, o_act = 0.3, 0.1
+    sigma = (6 * math.log(o_act / 0.005)) ** (1 / 6)
+    assert abs(sigma - 1.6185) < 1e-3
+    for b, hit, traversed in [(s * sigma * 0.999, True, 1), (s * sigma * 1.001, False, 0)]:
+        oc, _ = _one_gaussian(orc, syn, s, o_act, b)
+        out = oc.raytrace(False)
+        assert (out["output_transmittance"][0, 0, 0, 0] < 1.0) == hit
+        assert out["num_traversed"][0, 0] == traversed  # at 1.001 the ray also misses the unit cube
+    # inside the cube's corner region but outside the unit sphere: intersection program invoked, hit clipped
+    oc, g = _one_gaussian(orc, syn, s, o_act, 0.0)
+    g["mean"] = np.array([[3.0, 0.75 * s * sigma, 0.75 * s * sigma]])
+    oc.set_gaussians(g)
+    oc.update_bvh()
+    out = oc.raytrace(False)
+    assert out["num_traversed"][0, 0] == 1 and out["output_transmittance"][0, 0, 0, 0] == 1.0
+    # at the clip radius alpha equals MAX_ALPHA * alpha_threshold
+    oc, _ = _one_gaussian(orc, syn, s, o_act, s * sigma * (1 - 1e-9))
+    out = oc.raytrace(False)
+    np.testing.assert_allclose(1 - out["output_transmittance"][0, 0, 0, 0], MAX_ALPHA * 0.005, rtol=1e-5)
+
+
+def test_opacity_below_alpha_threshold_is_invisible(orc, syn):
+    oc, _ = _one_gaussian(orc, syn, o_act=0.004, b=0.0)
+    out = oc.raytrace(False)
+    assert out["num_traversed"][0, 0] == 0 and out["output_transmittance"][0, 0, 0, 0] == 1.0
+    assert oc.instances()[3][0] == 0
+
+
+def test_gaussian_behind_camera_rejected_but_counted(orc, syn):
+    # centre behind the origin but cube straddles it: dot(lo, ld) > 0 -> rejected after the counter (shaders.cu:33-38)
+    oc, _ = _one_gaussian(orc, syn, s=0.3, o_act=0.5, b=0.0, t=-0.2)
+    out = oc.raytrace(False)
+    assert out["num_traversed"][0, 0] == 1 and out["output_transmittance"][0, 0, 0, 0] == 1.0
+
+
+def test_near_plane_quirk_q1_total_transmittance_includes_hit_before_tmin(orc, syn):
+    """Response point at t=0.05 < znear=0.2 but the cube reaches past znear: counted in T_total, not composited."""
+    oc, _ = _one_gaussian(orc, syn, s=0.2, o_act=0.5, b=0.0, t=0.05)
+    cam = syn.plus_x_camera()
+    oc.set_camera(cam["origin"], cam["c2w"], cam["fov"], znear=0.2)
+    out = oc.raytrace(False)
+    alpha = MAX_ALPHA * 0.5
+    np.testing.assert_allclose(out["output_total_transmittance"][0, 0, 0, 0], 1 - alpha, rtol=1e-6)
+    assert out["output_transmittance"][0, 0, 0, 0] == 1.0 and out["num_accumulated"][0, 0] == 0
+    # nothing composited: rem = T - T_total = alpha, but remaining_X = 0/eps = 0 -> outputs stay 0
+    assert np.all(out["output_rgb"][0] == 0)
+
+
+def test_truncated_pair_tail_renormalisation(orc, syn):
+    """Two co-linear Gaussians, transmittance_threshold above T_1: out = C_1 * (1 + rem/(1-T_1)), forward_pass.cu:142-155."""
+    cam = syn.plus_x_camera()
+    oc = orc.Oracle(1, 1, double=True, use_bvh=False)
+    oc.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+    oc.set_config(jitter_primary_rays=0, num_bounces=0, transmittance_threshold=0.6)
+    lg = lambda p: math.log(p / (1 - p))
+    g = dict(rgb=np.array([[0.2, 0.4, 0.6], [0.9, 0.1, 0.5]]), normal=np.array([[-1.0, 0, 0], [0, 1.0, 0]]),
+             f0=np.full((2, 3), 0.04), roughness=np.array([[0.3], [0.8]]), opacity=np.array([[lg(0.5)], [lg(0.7)]]),
+             scale=np.full((2, 3), math.log(0.2)), mean=np.array([[2.0, 0, 0], [3.0, 0, 0]]), rotation=np.array([[1.0, 0, 0, 0]] * 2))
+    oc.set_gaussians(g)
+    oc.update_bvh()
+    out = oc.raytrace(False)
+    a1, a2 = MAX_ALPHA * 0.5, MAX_ALPHA * 0.7
+    T1, Ttot = 1 - a1, (1 - a1) * (1 - a2)
+    assert out["num_accumulated"][0, 0] == 1 and out["num_traversed"][0, 0] == 2
+    np.testing.assert_allclose(out["output_transmittance"][0, 0, 0, 0], T1, rtol=1e-12)
+    np.testing.assert_allclose(out["output_total_transmittance"][0, 0, 0, 0], Ttot, rtol=1e-12)
+    C1 = np.array([0.2, 0.4, 0.6]) * a1
+    np.testing.assert_allclose(out["output_rgb"][0, 0, 0], C1 * (1 + (T1 - Ttot) / (1 - T1)), rtol=1e-12)
+    np.testing.assert_allclose(out["output_depth"][0, 0, 0, 0], 2.0 * a1 * (1 + (T1 - Ttot) / (1 - T1)), rtol=1e-12)
+
+
+def test_sorting_is_by_distance_not_by_insertion(orc, syn):
+    cam = syn.plus_x_camera()
+    lg = lambda p: math.log(p / (1 - p))
+    res = []
+    for order in ([0, 1, 2], [2, 0, 1]):
+        oc = orc.Oracle(1, 1, double=True, use_bvh=False)
+        oc.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+        oc.set_config(jitter_primary_rays=0, num_bounces=0, transmittance_threshold=0.0)
+        mean = np.array([[4.0, 0, 0], [2.0, 0, 0], [3.0, 0, 0]])[order]
+        rgb = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]])[order]
+        g = dict(rgb=rgb, normal=np.zeros((3, 3)), f0=np.zeros((3, 3)), roughness=np.zeros((3, 1)), opacity=np.full((3, 1), lg(0.5)),
+                 scale=np.full((3, 3), math.log(0.2)), mean=mean, rotation=np.array([[1.0, 0, 0, 0]] * 3))
+        oc.set_gaussians(g)
+        oc.update_bvh()
+        res.append(oc.raytrace(False)["output_rgb"][0, 0, 0])
+    a = MAX_ALPHA * 0.5
+    np.testing.assert_allclose(res[0], [a * (1 - a) ** 2, a, a * (1 - a)], rtol=1e-12)  # green (t=2) first
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-12)
+
+
+def test_more_than_sixteen_hits_batches(orc, syn):
+    """40 co-linear Gaussians exercise the 16-at-a-time selection (forward_pass.cu:55-137)."""
+    cam = syn.plus_x_camera()
+    n = 40
+    rng = np.random.default_rng(3)
+    t = rng.permutation(n) * 0.1 + 1.0
+    oc = orc.Oracle(1, 1, double=True, use_bvh=False)
+    oc.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+    oc.set_config(jitter_primary_rays=0, num_bounces=0, transmittance_threshold=0.0)
+    g = dict(rgb=rng.uniform(0, 1, (n, 3)), normal=np.zeros((n, 3)), f0=np.zeros((n, 3)), roughness=np.zeros((n, 1)),
+             opacity=np.full((n, 1), math.log(0.05 / 0.95)), scale=np.full((n, 3), math.log(0.02)),
+             mean=np.stack([t, np.zeros(n), np.zeros(n)], 1), rotation=np.array([[1.0, 0, 0, 0]] * n))
+    oc.set_gaussians(g)
+    oc.update_bvh()
+    out = oc.raytrace(False)
+    a = MAX_ALPHA * 0.05
+    order = np.argsort(t)
+    T, C = 1.0, np.zeros(3)
+    for i in order:
+        C += g["rgb"][i] * (T * a)
+        T *= 1 - a
+    assert out["num_accumulated"][0, 0] == n
+    np.testing.assert_allclose(out["output_rgb"][0, 0, 0], C, rtol=1e-10)  # T == T_total -> no tail term
+    np.testing.assert_allclose(out["output_transmittance"][0, 0, 0, 0], T, rtol=1e-10)
+
+
+# ------------------------------------------------------------------ BRDF (utils/ggx_brdf.h)
+def test_cook_torrance_weight_zero_f0_is_zero(orc):
+    w = orc.cook_torrance_weight([0, 0, 1], [0.3, 0, 0.95], [-0.3, 0, 0.95], 0.2, [0, 0, 0])
+    assert np.all(w == 0)
+
+
+def test_near_mirror_sample_is_reflection(orc):
+    N = np.array([0.0, 0.6, 0.8])
+    V = np.array([0.3, -0.2, 0.9])
+    V /= np.linalg.norm(V)
+    L = orc.sample_cook_torrance(N, V, 0.01, 0.37, 0.61)
+    R = 2 * N * np.dot(N, V) - V
+    assert np.abs(L - R).max() < 1e-3
+    assert abs(np.linalg.norm(L) - 1) < 1e-5
+
+
+def test_sample_cook_torrance_formula(orc):
+    N = np.array([0.0, 0.0, 1.0])  # N.z >= 0.999 -> tangent frame from (1,0,0)
+    V = np.array([0.6, 0.0, 0.8])
+    r, u1, u2 = 0.5, 0.25, 0.4
+    a = r * r
+    phi = 2 * math.pi * u1
+    ct = math.sqrt((1 - u2) / (1 + (a * a - 1) * u2))
+    st = math.sqrt(1 - ct * ct)
+    T = np.cross([1.0, 0, 0], N)
+    T /= np.linalg.norm(T)
+    B = np.cross(N, T)
+    Hh = st * math.cos(phi) * T + st * math.sin(phi) * B + ct * N
+    L = -V - 2 * Hh * np.dot(Hh, -V)
+    assert np.abs(orc.sample_cook_torrance(N, V, r, u1, u2) - L).max() < 1e-6
+
+
+def test_cook_torrance_weight_formula(orc):
+    N = np.array([0.0, 0.0, 1.0]); V = np.array([0.6, 0.0, 0.8]); L = np.array([-0.48, 0.36, 0.8]); f0 = np.array([0.04, 0.5, 0.9]); r = 0.4
+    Hh = (V + L) / np.linalg.norm(V + L)
+    k = (r * r) ** 2 / 2
+    G1 = lambda w: max(N @ w, 0) / (max(N @ w, 0) * (1 - k) + k + 1e-8)
+    F = f0 + (1 - f0) * (1 - max(V @ Hh, 0)) ** 5
+    ref = F * G1(V) * G1(L) * max(V @ Hh, 0) / (max(N @ Hh, 0) * max(N @ V, 0) + 1e-8)
+    assert np.abs(orc.cook_torrance_weight(N, V, L, r, f0) - ref).max() < 1e-5
+
+
+def test_downward_normal_yields_nan_like_reference(orc):
+    """ggx_brdf.h:163 builds the tangent from (0,0,1) whenever N.z < 0.999, including N=(0,0,-1): NaN. Kept."""
+    L = orc.sample_cook_torrance([0, 0, -1.0], [0, 0.6, -0.8], 0.2, 0.3, 0.3)
+    assert np.all(np.isnan(L))
+
+
+# ------------------------------------------------------------------ structure
+def test_bvh_and_brute_force_agree_on_primary_rays(orc, syn):
+    g = syn.make_scene(3000, "trained", seed=1)
+    cam = syn.default_camera()
+    outs = []
+    for ub in (True, False):
+        o = orc.Oracle(48, 27, use_bvh=ub)
+        o.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+        o.set_gaussians(g)
+        o.update_bvh()
+        o.set_config(jitter_primary_rays=0, num_bounces=0)
+        outs.append(o.raytrace(False))
+    assert np.array_equal(outs[0]["num_traversed"], outs[1]["num_traversed"])
+    assert np.array_equal(outs[0]["num_accumulated"], outs[1]["num_accumulated"])
+    assert np.abs(outs[0]["output_rgb"] - outs[1]["output_rgb"]).max() < 1e-6
+
+
+def test_no_outputs_needed_for_unexecuted_steps(orc, syn):
+    oc, _ = _one_gaussian(orc, syn)
+    out = oc.raytrace(False)
+    assert np.all(out["output_transmittance"][1:] == 1) and np.all(out["output_total_transmittance"][1:] == 1)
+    assert np.all(out["output_rgb"][1:] == 0) and np.all(out["output_ray_direction"] == 0)
+    np.testing.assert_array_equal(out["output_final"][0], out["output_rgb"][0])
+
+
+def test_accumulate_samples_running_mean(orc, syn):
+    g = syn.make_scene(1500, "trained", seed=2)
+    cam = syn.default_camera()
+    o = orc.Oracle(24, 16, double=True)
+    o.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+    o.set_gaussians(g)
+    o.update_bvh()
+    o.set_config(num_bounces=0, jitter_primary_rays=1)
+    singles = [o.raytrace(False)["output_rgb"].copy() for _ in range(3)]
+    o2 = orc.Oracle(24, 16, double=True)
+    o2.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+    o2.set_gaussians(g)
+    o2.update_bvh()
+    o2.set_config(num_bounces=0, jitter_primary_rays=1, accumulate_samples=1)
+    for k in range(3):
+        acc = o2.raytrace(False)
+        np.testing.assert_allclose(acc["output_rgb"], np.mean(singles[: k + 1], axis=0), atol=1e-12)
+        np.testing.assert_allclose(acc["output_final"][0], acc["output_rgb"].sum(0), atol=1e-12)
