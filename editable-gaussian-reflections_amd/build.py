@@ -1,0 +1,88 @@
+"""In-tree build of the two native artefacts (no cmake, no JIT cache):
+
+  build/libegr_hip.so    hipcc --offload-arch=gfx950   csrc/{trace,epilogue,bvh,api}.hip     the C-ABI product (include/egr_raytracer.h)
+  build/libraytracer.so  g++ against the installed torch  csrc/torch_binding.cpp      TORCH_LIBRARY(raytracer) shim
+
+hipcc cross-compiles gfx950 without a GPU; both .so files travel to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "build")
+ROOT = os.path.dirname(HERE)
+HIP_LIB = os.path.join(OUT, "libegr_hip.so")
+TORCH_LIB = os.path.join(OUT, "libraytracer.so")
+
+HIPCC = os.environ.get("HIPCC", shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+HIP_SOURCES = ["trace.hip", "epilogue.hip", "bvh.hip", "api.hip"]
+EXTRA_FLAGS = {"epilogue.hip": ["-ffp-contract=off"]}  # see the note at the top of csrc/epilogue.hip
+HEADERS = [os.path.join(CSRC, "egr_internal.hpp"), os.path.join(CSRC, "egr_device.hpp"), os.path.join(CSRC, "egr_state.hpp"), os.path.join(ROOT, "include", "egr_raytracer.h")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
+        raise RuntimeError("native build failed: " + os.path.basename(cmd[0]))
+    return r.stdout
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    objs = []
+    relink = force
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OUT, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + HEADERS):
+            if verbose:
+                print("hipcc", src, flush=True)
+            _run([HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
+            relink = True
+        objs.append(o)
+    if relink or not os.path.exists(HIP_LIB):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB])
+    return HIP_LIB
+
+
+def build_torch(force=False, verbose=False):
+    import torch
+    from torch.utils import cpp_extension
+
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    if not (force or _newer(TORCH_LIB, [src, HIP_LIB] + HEADERS)):
+        return TORCH_LIB
+    tdir = os.path.dirname(torch.__file__)
+    inc = cpp_extension.include_paths()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+    cmd += ["-I" + p for p in inc] + ["-I" + os.path.join(rocm, "include")]
+    cmd += [src, "-o", TORCH_LIB, "-L" + os.path.join(tdir, "lib"), "-L" + OUT, "-legr_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+            "-ltorch", "-Wl,-rpath,$ORIGIN", "-Wl,--no-as-needed"]
+    if verbose:
+        print("g++ torch_binding.cpp", flush=True)
+    _run(cmd)
+    return TORCH_LIB
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_torch(force, verbose)
+    return HIP_LIB, TORCH_LIB
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,223 @@
+// extern "C" surface of libegr_hip.so (see include/egr_raytracer.h). Host-only code; the kernels live in
+// bvh.hip and trace.hip. The product fails loudly: every HIP error becomes a non-zero return + message.
+#include <cstdio>
+#include <cstring>
+
+#include "egr_internal.hpp"
+
+void egr_copy_final_to_denoised(egr_context *c, hipStream_t s);
+
+void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s) {
+    if (!c->timing) return;
+    if (c->stamps_used == c->stamps.size()) {
+        KernelStamp k{name, nullptr, nullptr};
+        EGR_HIP(hipEventCreate(&k.start));
+        EGR_HIP(hipEventCreate(&k.stop));
+        c->stamps.push_back(k);
+    }
+    c->stamps[c->stamps_used].name = name;
+    EGR_HIP(hipEventRecord(c->stamps[c->stamps_used].start, s));
+}
+void egr_stamp_end(egr_context *c, hipStream_t s) {
+    if (!c->timing) return;
+    EGR_HIP(hipEventRecord(c->stamps[c->stamps_used].stop, s));
+    c->stamps_used++;
+}
+
+namespace {
+template <class F> int guarded(egr_context *c, F &&f) {
+    try {
+        int prev = 0;
+        EGR_HIP(hipGetDevice(&prev));
+        if (prev != c->device) EGR_HIP(hipSetDevice(c->device));
+        f();
+        if (prev != c->device) EGR_HIP(hipSetDevice(prev));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) throw EgrCheck{e, "kernel launch"};
+        return 0;
+    } catch (const EgrCheck &e) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "libegr_hip: %s failed: %s", e.what, hipGetErrorString(e.e));
+        c->last_error = buf;
+        return 1;
+    } catch (const std::exception &e) {
+        c->last_error = std::string("libegr_hip: ") + e.what();
+        return 1;
+    }
+}
+} // namespace
+
+extern "C" {
+
+const char *egr_version(void) { return "egr-hip 0.1 (gfx950)"; }
+
+int egr_create(egr_context **out, int device, int width, int height, int64_t ppll_forward_size, int64_t ppll_backward_size) {
+    if (!out || width <= 0 || height <= 0) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "libegr_hip: no HIP device available (this library has no CPU fallback)\n");
+        return 2;
+    }
+    egr_context *c = new egr_context();
+    c->device = device, c->width = width, c->height = height;
+    c->fwd_capacity = ppll_forward_size > 0 ? ppll_forward_size : 1, c->bwd_capacity = ppll_backward_size > 0 ? ppll_backward_size : 1;
+    int rc = guarded(c, [&] {
+        egr_trace_alloc(c);
+        EGR_HIP(hipEventCreate(&c->ev_rt0)), EGR_HIP(hipEventCreate(&c->ev_rt1));
+        EGR_HIP(hipEventCreate(&c->ev_ub0)), EGR_HIP(hipEventCreate(&c->ev_ub1));
+    });
+    if (rc) {
+        fprintf(stderr, "%s\n", c->last_error.c_str());
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+void egr_destroy(egr_context *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    egr_trace_free(c);
+    egr_bvh_free(c);
+    for (auto &k : c->stamps) (void)hipEventDestroy(k.start), (void)hipEventDestroy(k.stop);
+    if (c->ev_rt0) (void)hipEventDestroy(c->ev_rt0), (void)hipEventDestroy(c->ev_rt1), (void)hipEventDestroy(c->ev_ub0), (void)hipEventDestroy(c->ev_ub1);
+    delete c;
+}
+
+int egr_bind(egr_context *c, const egr_camera *camera, const egr_config *config, const egr_framebuffer *framebuffer,
+             const egr_metadata *metadata, const egr_stats *stats) {
+    if (!c || !camera || !config || !framebuffer || !metadata || !stats) return 1;
+    c->cam = *camera, c->cfg = *config, c->fb = *framebuffer, c->meta = *metadata, c->stats = *stats;
+    c->bound = true;
+    return 0;
+}
+
+int egr_set_gaussians(egr_context *c, const egr_gaussians *g) {
+    if (!c || !g) return 1;
+    c->g = *g;
+    c->have_gaussians = true;
+    return guarded(c, [&] { egr_bvh_reserve(c, g->count); });
+}
+
+int egr_set_partition(egr_context *c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return 1;
+    c->rank = rank, c->world = world;
+    return 0;
+}
+
+static int require_ready(egr_context *c, bool need_bvh) {
+    if (!c->bound || !c->have_gaussians) {
+        c->last_error = "libegr_hip: egr_bind / egr_set_gaussians must be called first";
+        return 1;
+    }
+    if (need_bvh && (!c->bvh_valid || c->n_built != c->g.count)) {
+        c->last_error = "libegr_hip: BVH is missing or was built for a different gaussian count; call egr_rebuild_bvh";
+        return 1;
+    }
+    return 0;
+}
+
+int egr_rebuild_bvh(egr_context *c, void *stream) {
+    if (!c || require_ready(c, false)) return 1;
+    return guarded(c, [&] { egr_bvh_rebuild(c, (hipStream_t)stream); });
+}
+
+int egr_update_bvh(egr_context *c, void *stream) {
+    if (!c || require_ready(c, true)) return 1;
+    return guarded(c, [&] {
+        hipStream_t s = (hipStream_t)stream;
+        if (c->timing) EGR_HIP(hipEventRecord(c->ev_ub0, s));
+        egr_bvh_refit(c, s);
+        if (c->timing) EGR_HIP(hipEventRecord(c->ev_ub1, s)), c->have_ub = true;
+    });
+}
+
+int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
+    if (!c || require_ready(c, true)) return 1;
+    return guarded(c, [&] {
+        hipStream_t s = (hipStream_t)stream;
+        c->stamps_used = 0;
+        if (c->timing) EGR_HIP(hipEventRecord(c->ev_rt0, s));
+        egr_trace_launch(c, grads_enabled != 0, s);
+        if (c->timing) EGR_HIP(hipEventRecord(c->ev_rt1, s)), c->have_rt = true;
+    });
+}
+
+int egr_denoise(egr_context *c, void *stream) {
+    if (!c || require_ready(c, false)) return 1;
+    return guarded(c, [&] { egr_copy_final_to_denoised(c, (hipStream_t)stream); });
+}
+
+int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
+    if (!c || !out) return 1;
+    return guarded(c, [&] {
+        EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
+        const uint32_t *w = c->control_host;
+        auto u64 = [&](int i) { return (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32); };
+        out->rays = u64(CW_RAYS), out->rays_step0 = u64(CW_RAYS0), out->candidates = u64(CW_CAND);
+        out->composited = u64(CW_COMP), out->composited_step0 = u64(CW_COMP0);
+        out->status = w[CW_STATUS];
+        out->bvh_depth = c->max_depth;
+    });
+}
+
+int egr_enable_timing(egr_context *c, int enable) {
+    if (!c) return 1;
+    c->timing = enable != 0;
+    c->have_rt = c->have_ub = false;
+    c->stamps_used = 0;
+    return 0;
+}
+float egr_last_raytrace_ms(egr_context *c) {
+    if (!c || !c->have_rt) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(c->ev_rt1) != hipSuccess || hipEventElapsedTime(&ms, c->ev_rt0, c->ev_rt1) != hipSuccess) return -1.0f;
+    return ms;
+}
+float egr_last_update_bvh_ms(egr_context *c) {
+    if (!c || !c->have_ub) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(c->ev_ub1) != hipSuccess || hipEventElapsedTime(&ms, c->ev_ub0, c->ev_ub1) != hipSuccess) return -1.0f;
+    return ms;
+}
+int egr_last_kernel_ms(egr_context *c, float *ms, const char **names, int max_entries) {
+    if (!c) return 0;
+    int n = 0;
+    for (size_t i = 0; i < c->stamps_used && n < max_entries; i++) {
+        float t = -1.0f;
+        if (hipEventSynchronize(c->stamps[i].stop) != hipSuccess) break;
+        if (hipEventElapsedTime(&t, c->stamps[i].start, c->stamps[i].stop) != hipSuccess) break;
+        ms[n] = t;
+        if (names) names[n] = c->stamps[i].name;
+        n++;
+    }
+    return n;
+}
+
+int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, void *stream) {
+    if (!c) return 1;
+    return guarded(c, [&] {
+        EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
+        size_t n = c->n_built;
+        if (M) EGR_HIP(hipMemcpy(M, c->inst_m, n * 12 * sizeof(float), hipMemcpyDeviceToHost));
+        if (W) EGR_HIP(hipMemcpy(W, c->inst_w, n * 12 * sizeof(float), hipMemcpyDeviceToHost));
+        if (aabb) EGR_HIP(hipMemcpy(aabb, c->aabb, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int egr_debug_check_bvh(egr_context *c, void *stream) {
+    if (!c) return 1;
+    int bad = 0;
+    int rc = guarded(c, [&] {
+        std::string msg;
+        bad = egr_bvh_check(c, (hipStream_t)stream, msg);
+        if (bad) c->last_error = "libegr_hip: BVH check failed: " + msg;
+    });
+    return rc ? rc : bad;
+}
+
+const char *egr_last_error(egr_context *c) { return c ? c->last_error.c_str() : "libegr_hip: null context"; }
+
+} // extern "C"

@@ -1,0 +1,147 @@
+// Internal declarations shared by the HIP translation units of libegr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/egr_raytracer.h"
+
+#define EGR_NSTEPS EGR_NUM_STEPS
+#define EGR_WAVE 64
+#define EGR_TILE 8            // one wave = one 8x8 pixel tile
+#define EGR_MACRO_TILE 16     // multi-GPU partition granule (2x2 wave tiles)
+#define EGR_INTERNAL_NODE 0xFFFFFFFFu
+#define EGR_HIT_BLOCK_ROWS 8  // composited-hit arena block: 8 rows x 64 lanes x 16 B (+1 header row)
+#define EGR_MAX_DEPTH_BINS 256
+
+struct EgrCheck {
+    hipError_t e;
+    const char *what;
+};
+inline void egr_hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw EgrCheck{e, what};
+}
+#define EGR_HIP(expr) egr_hip_check((expr), #expr)
+
+// ---- per-Gaussian records (internal layout in HBM) -----------------------------------------------------
+// inst_w : float4[3N]   rows of W = M^-1 (world->object), snapshot at update/rebuild      48 B
+// inst_m : float4[3N]   rows of M   (object->world),      snapshot at update/rebuild      48 B
+// app    : float4[3N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y) (f0.z, rough, opacity, sigma) 48 B
+// nodes  : float4[2*(2N-1)] threaded pre-order LBVH: (lo.xyz, skip) (hi.xyz, prim|INTERNAL)  32 B / node
+
+struct DeviceView { // everything a kernel needs, passed by value
+    int width, height, tiles_x, tiles_y;
+    uint32_t num_pixels;
+    uint32_t n;          // gaussians
+    uint32_t num_nodes;  // 2n-1 (0 if n == 0)
+    // partition
+    int rank, world;
+    uint32_t num_tasks;  // wave tiles owned by this rank
+    egr_gaussians g;
+    egr_config cfg;
+    egr_camera cam;
+    egr_framebuffer fb;
+    egr_metadata meta;
+    egr_stats stats;
+    const float4 *nodes;
+    const float4 *inst_w;
+    const float4 *inst_m;
+    const float4 *app;
+    // per-launch scratch
+    float *cand_keys;      // [slots][cand_cap][64]
+    float2 *cand_vals;     // [slots][cand_cap][64]  (alpha, gaussian id bits)
+    uint32_t cand_cap;
+    uint32_t num_slots;    // resident waves
+    float4 *hit_arena;     // blocks of (1 + EGR_HIT_BLOCK_ROWS) rows x 64 lanes
+    uint32_t hit_blocks_cap;
+    uint32_t *task_last_block; // [NSTEPS][num_task_slots]  last arena block of the task (or ~0u)
+    float *state;          // internal per-ray state, SoA by task-linear index (see trace.hip)
+    uint32_t state_stride; // = padded number of task-linear rays
+    uint32_t *control;     // device counters (see ControlWord)
+};
+
+enum ControlWord : int {
+    CW_QUEUE0 = 0,      // task queue heads, one per step kernel (forward 0..2, backward 3..5, finish 6)
+    CW_HIT_BUMP = 8,    // arena block bump allocator
+    CW_STATUS = 9,
+    CW_RAYS = 10,       // 64-bit counters take two words each
+    CW_RAYS0 = 12,
+    CW_CAND = 14,
+    CW_COMP = 16,
+    CW_COMP0 = 18,
+    CW_COUNT = 32
+};
+
+struct KernelStamp {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+struct egr_context {
+    int device = 0;
+    int width = 0, height = 0;
+    int64_t fwd_capacity = 0, bwd_capacity = 0;
+    int rank = 0, world = 1;
+    bool bound = false, have_gaussians = false, bvh_valid = false;
+    egr_gaussians g{};
+    egr_config cfg{};
+    egr_camera cam{};
+    egr_framebuffer fb{};
+    egr_metadata meta{};
+    egr_stats stats{};
+    // BVH
+    uint32_t n_alloc = 0;      // capacity of per-gaussian buffers
+    uint32_t n_built = 0;      // n the tree topology was built for
+    float4 *nodes = nullptr, *inst_w = nullptr, *inst_m = nullptr, *app = nullptr;
+    float *aabb = nullptr;             // [n][6] instance boxes (lo, hi)
+    uint32_t *leaf_pre = nullptr;      // [n] pre-order index of gaussian i's leaf
+    uint32_t *depth_order = nullptr;   // [n-1] internal nodes (pre-order idx) grouped by depth
+    std::vector<uint32_t> depth_start; // host: bucket offsets, size max_depth+2
+    uint32_t max_depth = 0;
+    // build temporaries
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint64_t *keys_in = nullptr, *keys_out = nullptr;
+    uint32_t *vals_in = nullptr, *vals_out = nullptr;
+    int32_t *k_left = nullptr, *k_right = nullptr, *k_parent = nullptr; // Karras arrays (index space: internal i, leaf n-1+j)
+    uint32_t *k_first = nullptr, *k_last = nullptr;
+    uint32_t *node_depth = nullptr;
+    uint32_t *scratch_u32 = nullptr; // bounds (6), depth histogram, cursors
+    // launch scratch
+    float *cand_keys = nullptr;
+    float2 *cand_vals = nullptr;
+    uint32_t cand_cap = 0, num_slots = 0;
+    float4 *hit_arena = nullptr;
+    uint32_t hit_blocks_cap = 0;
+    uint32_t *task_last_block = nullptr;
+    float *state = nullptr;
+    uint32_t state_stride = 0;
+    uint32_t num_tasks_total = 0; // wave tiles in the whole image
+    uint32_t *control = nullptr;
+    uint32_t *control_host = nullptr; // pinned
+    // timing
+    bool timing = false;
+    hipEvent_t ev_rt0 = nullptr, ev_rt1 = nullptr, ev_ub0 = nullptr, ev_ub1 = nullptr;
+    bool have_rt = false, have_ub = false;
+    std::vector<KernelStamp> stamps;
+    size_t stamps_used = 0;
+    std::string last_error;
+};
+
+// bvh.hip
+void egr_bvh_free(egr_context *c);
+void egr_bvh_reserve(egr_context *c, uint32_t n);
+void egr_bvh_rebuild(egr_context *c, hipStream_t s);
+void egr_bvh_refit(egr_context *c, hipStream_t s);
+int egr_bvh_check(egr_context *c, hipStream_t s, std::string &msg);
+// trace.hip
+void egr_trace_alloc(egr_context *c);
+void egr_trace_free(egr_context *c);
+void egr_trace_launch(egr_context *c, bool grads, hipStream_t s);
+uint32_t egr_num_tasks_for_rank(const egr_context *c);
+DeviceView egr_make_view(const egr_context *c);
+// timing helpers (api.hip)
+void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s);
+void egr_stamp_end(egr_context *c, hipStream_t s);

@@ -1,0 +1,653 @@
+// The hot path: __raygen__rg + __intersection__gaussian + forward_pass + backward_pass of the reference
+// (shaders.cu:9-173, forward_pass.cu:3-155, backward_pass.cu:3-222) as hand-written HIP kernels for gfx950.
+//
+// Structure (MI355X-first; nothing here is a translation of the OptiX pipeline):
+//   * one wave64 = one 8x8 pixel tile, one lane = one ray; PERSISTENT waves pull tiles from an atomic queue
+//     (ragged per-ray work: 1..1000s of candidates), one workgroup = one wave so waves never wait on each other;
+//   * the path is split per bounce step (k_forward<step>), not fused into one megakernel: per-ray state lives in
+//     a task-linear SoA buffer (fully coalesced), registers stay low, occupancy high;
+//   * traversal of the threaded pre-order LBVH is STACKLESS (hit -> node+1, miss -> skip), "while-while":
+//     every lane first advances to its next leaf, then all lanes evaluate their candidate together;
+//   * the reference's global per-pixel linked list (one same-address atomic per candidate, 36 B entries,
+//     pointer chasing) is replaced by a per-resident-wave candidate scratch, lane-interleaved [k][lane] so
+//     every access of the wave is one contiguous 256-B row; it is reused tile after tile and stays in L2/MALL;
+//   * depth ordering = repeated strict-successor selection over the (coalesced) key rows; semantically the
+//     reference's 16-at-a-time k-buffer (forward_pass.cu:55-137) without its batch-boundary tie drop;
+//   * composited hits needed by the backward pass go to an arena in 8-row blocks (one atomic per 8 rows per
+//     WAVE instead of one per hit per lane), chained newest->oldest, which is the order backward walks;
+//   * backward recomputes the local hit point from the snapshot transform instead of storing it (it needs W
+//     and M anyway), then issues the same 15/22 float atomics per hit as backward_pass.cu:210-220.
+#include <algorithm>
+#include <cstdio>
+
+#include "egr_state.hpp"
+
+namespace {
+
+EGR_DI uint32_t wave_next_task(uint32_t *queue) {
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(queue, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+}
+EGR_DI uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+    return x;
+}
+EGR_DI uint32_t wave_max_u32(uint32_t x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, off));
+    return x;
+}
+EGR_DI void add64(uint32_t *ctrl, int word, uint32_t x) {
+    if (x) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + word), (unsigned long long)x);
+}
+
+// T4: primary ray (core/camera.h:17-36). Draw order: jitter.x then jitter.y.
+EGR_DI f3 primary_direction(const DeviceView &v, int ix, int iy, bool jitter, uint32_t &seed) {
+    float view_size = tanf(*v.cam.vertical_fov_radians / 2.0f);
+    float aspect_ratio = (float)v.width / (float)v.height;
+    float fx = (float)ix, fy = (float)iy;
+    if (jitter) {
+        float jx = rnd(seed) - 0.5f;
+        float jy = rnd(seed) - 0.5f;
+        fx += jx;
+        fy += jy;
+    }
+    float y = view_size * (1.0f - 2.0f * (fy + 0.5f) / (float)v.height);
+    float x = aspect_ratio * view_size * (2.0f * (fx + 0.5f) / (float)v.width - 1.0f);
+    const float *w = v.cam.rotation_w2c; // rows of w2c (= columns of c2w)
+    f3 w0 = mk3(w[0], w[1], w[2]), w1 = mk3(w[3], w[4], w[5]), w2 = mk3(w[6], w[7], w[8]);
+    return normalize(w0 * x + w1 * y - w2);
+}
+
+// Object-space quantities of one (ray, gaussian) pair; shared by forward (R2) and backward (recompute).
+struct LocalHit {
+    f3 lo, ld;      // object-space origin / un-normalised direction
+    f3 dhat;        // normalised object-space direction
+    float t;        // world distance of the max-response point
+    f3 u;           // unscaled local hit
+};
+EGR_DI void object_ray(const float4 *__restrict__ inst_w, uint32_t gid, f3 o, f3 d, f3 &lo, f3 &ld) {
+    float4 w0 = inst_w[3 * gid], w1 = inst_w[3 * gid + 1], w2 = inst_w[3 * gid + 2];
+    lo = mk3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
+             w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
+    ld = mk3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z, w2.x * d.x + w2.y * d.y + w2.z * d.z);
+}
+EGR_DI void closest_point(f3 lo, f3 ld, f3 &dhat, float &t, f3 &u) { // shaders.cu:41-45
+    float norm = length(ld);
+    dhat = ld * (1.0f / norm);
+    float tl = dot(-lo, dhat);
+    t = tl / norm;
+    u = lo + tl * dhat;
+}
+// OptiX's instance test restated: segment [tmin,tmax] of the object-space ray vs the unit cube.
+EGR_DI bool hits_unit_cube(f3 lo, f3 ld, float tmin, float tmax) {
+    f3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+    float t0 = tmin, t1 = tmax;
+    bool ok = true;
+#define EGR_AXIS(c)                                                            \
+    if (ld.c != 0.0f) {                                                        \
+        float a = (-1.0f - lo.c) * inv.c, b = (1.0f - lo.c) * inv.c;           \
+        t0 = fmaxf(t0, fminf(a, b));                                           \
+        t1 = fminf(t1, fmaxf(a, b));                                           \
+    } else if (lo.c < -1.0f || lo.c > 1.0f)                                    \
+        ok = false;
+    EGR_AXIS(x) EGR_AXIS(y) EGR_AXIS(z)
+#undef EGR_AXIS
+    return ok && t0 <= t1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-launch prologue: Raytracer::raytrace host part (raytracer.cpp:82-86), on the device, no host sync
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_prologue(DeviceView v, int grads) {
+    int t = threadIdx.x;
+    if (t < CW_COUNT) v.control[t] = 0;
+    if (t == 0) {
+        *v.meta.grads_enabled = grads ? 1 : 0;   // metadata.h:29
+        *v.meta.total_num_calls += 1;             // metadata.h:30
+    }
+}
+__global__ void k_epilogue(DeviceView v, int grads) {
+    // raytracer.cpp:91-93 (the reference adds 1 whenever accumulate_samples is set)
+    if (threadIdx.x == 0 && *v.cfg.accumulate_samples) *v.fb.accumulated_sample_count += 1;
+}
+// per-launch live record: activated appearance + (opacity, sigma). Reads the CURRENT parameter tensors, like
+// the reference's read_* helpers do inside the launch (utils/helpers.cu:10-33), while inst_w/inst_m stay snapshots.
+__global__ void __launch_bounds__(256) k_live(DeviceView v) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.n) return;
+    const egr_gaussians &g = v.g;
+    float o = sigmoid_act(g.opacity[i]);
+    float sigma = compute_scaling_factor(o, *v.cfg.alpha_threshold, *v.cfg.exp_power);
+    float4 *app = const_cast<float4 *>(v.app);
+    app[3 * i] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
+    app[3 * i + 1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
+    app[3 * i + 2] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: one bounce step for every ray of this rank
+// ---------------------------------------------------------------------------------------------------------
+template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(DeviceView v, int step) {
+    const int lane = threadIdx.x;
+    float *__restrict__ keys = v.cand_keys + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
+    float2 *__restrict__ vals = v.cand_vals + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
+    const float4 *__restrict__ nodes = v.nodes;
+    const float4 *__restrict__ app = v.app;
+    const uint32_t END = v.num_nodes;
+
+    const float exp_power = *v.cfg.exp_power;
+    const float transmittance_threshold = *v.cfg.transmittance_threshold;
+    const float backfacing_max_dist = *v.cfg.backfacing_max_dist;
+    const float backfacing_thr = *v.cfg.backfacing_invalid_normal_threshold;
+    const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
+    const float far_plane = *v.cam.zfar;
+    const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
+    if (step > num_bounces) return;
+
+    uint32_t w_rays = 0, w_cand = 0, w_comp = 0;
+
+    for (;;) {
+        const uint32_t task = wave_next_task(v.control + CW_QUEUE0 + step);
+        if (task >= v.num_tasks) break;
+        const TaskGeom tg = task_geom(v, task, lane);
+        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
+        if (GRADS && lane == 0) v.task_last_block[(size_t)step * v.num_tasks + task] = 0xFFFFFFFFu; // nothing recorded yet
+
+        // ---- R1: ray for this step ----------------------------------------------------------------------
+        bool active = tg.inside;
+        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+        uint32_t seed = 0;
+        if (step == 0) {
+            if (active) {
+                seed = tea4(tg.pixel_id, (uint32_t)*v.meta.total_num_calls); // shaders.cu:88
+                ro = mk3(v.cam.origin[0], v.cam.origin[1], v.cam.origin[2]);
+                rd = primary_direction(v, tg.px, tg.py, *v.cfg.jitter_primary_rays != 0, seed);
+            }
+        } else {
+            active = active && S.ld(F_ALIVE) != 0.0f;
+            if (active) {
+                ro = S.ld3(F_RAY_O);
+                rd = S.ld3(F_RAY_D);
+                seed = f2u(S.ld(F_SEED));
+            }
+        }
+        if (__ballot(active) == 0ull) continue;
+
+        // ---- R2: traversal + candidate evaluation (shaders.cu:9-75) -------------------------------------
+        const bool ray_ok = active && finite3(ro) && finite3(rd); // NaN rays (ggx_brdf.h:163) hit nothing
+        const f3 inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        uint32_t node = ray_ok ? 0u : END;
+        uint32_t cnt = 0, traversed = 0;
+        float full_T = 1.0f;
+        bool overflow = false;
+        for (;;) {
+            uint32_t prim = EGR_INTERNAL_NODE;
+            while (node < END) { // advance to the next leaf whose box the segment overlaps
+                float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
+                bool hit = slab_hit(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), ro, inv, near_plane, far_plane);
+                uint32_t skip = f2u(n0.w), p = f2u(n1.w);
+                if (!hit) {
+                    node = skip;
+                } else if (p == EGR_INTERNAL_NODE) {
+                    node = node + 1;
+                } else {
+                    prim = p;
+                    node = skip;
+                    break;
+                }
+            }
+            if (__ballot(prim != EGR_INTERNAL_NODE) == 0ull) break;
+            if (prim != EGR_INTERNAL_NODE) {
+                f3 lo, ld;
+                object_ray(v.inst_w, prim, ro, rd, lo, ld);
+                if (hits_unit_cube(lo, ld, near_plane, far_plane)) {
+                    traversed++;                                        // shaders.cu:33
+                    if (!(dot(lo, ld) > 0.0f)) {                        // :36
+                        f3 dhat, u;
+                        float t;
+                        closest_point(lo, ld, dhat, t, u);              // :41-45
+                        float sq = dot(u, u);
+                        bool accept = !(sq > 1.0f);                     // :48-51
+                        if (accept && step != 0 && t < backfacing_max_dist) { // :54-61 (world normal . object dir)
+                            f3 gn = mk3(v.g.normal[3 * prim], v.g.normal[3 * prim + 1], v.g.normal[3 * prim + 2]);
+                            if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) accept = false;
+                        }
+                        if (accept) {
+                            float4 a2 = app[3 * prim + 2]; // (f0.z, roughness, opacity, sigma)
+                            f3 x = u * a2.w;                                     // :64
+                            float gaussval = eval_gaussian_sq(dot(x, x), exp_power); // :65
+                            float alpha = EGR_MAX_ALPHA * gaussval * a2.z;       // kernel.cu:14-16
+                            full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
+                            if (cnt < v.cand_cap) {
+                                keys[(size_t)cnt * EGR_WAVE + lane] = t;
+                                vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(prim));
+                                cnt++;
+                            } else {
+                                overflow = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- R3: depth-ordered compositing (forward_pass.cu:48-137) --------------------------------------
+        f3 c_rgb = mk3(0, 0, 0), c_n = mk3(0, 0, 0), c_f0 = mk3(0, 0, 0);
+        float c_rough = 0.0f, c_depth = 0.0f, T = 1.0f;
+        uint32_t nhits = 0;
+        {
+            float t_prev = near_plane;    // strict '>' against tmin (forward_pass.cu:62)
+            uint32_t k_prev = 0xFFFFFFFFu; // ties: continue in list order after the previous pick
+            bool running = active && cnt > 0;
+            uint32_t last_block = 0xFFFFFFFFu, cur_block = 0xFFFFFFFFu;
+            bool recording = GRADS;
+            for (uint32_t it = 0;; it++) {
+                // strict successor of (t_prev, k_prev) in (t, k) lexicographic order
+                float best = 3.4028235e38f;
+                uint32_t bi = 0xFFFFFFFFu;
+                if (running) {
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        float tk = keys[(size_t)k * EGR_WAVE + lane];
+                        bool after = (tk > t_prev) || (tk == t_prev && k > k_prev && k_prev != 0xFFFFFFFFu);
+                        if (after && tk < best) best = tk, bi = k;
+                    }
+                    if (bi == 0xFFFFFFFFu || !(best < far_plane)) running = false; // :81, :91-93
+                }
+                if (__ballot(running) == 0ull) break;
+                if (GRADS && (it % EGR_HIT_BLOCK_ROWS) == 0 && recording) { // one arena block per 8 rows per wave
+                    uint32_t blk = 0;
+                    if (lane == 0) blk = atomicAdd(v.control + CW_HIT_BUMP, 1u);
+                    blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
+                    if (blk >= v.hit_blocks_cap) {
+                        recording = false;
+                        if (lane == 0) atomicOr(v.control + CW_STATUS, EGR_STATUS_HIT_ARENA_OVERFLOW);
+                    } else {
+                        if (lane == 0) v.hit_arena[(size_t)blk * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE] = make_float4(u2f(last_block), 0, 0, 0);
+                        last_block = cur_block = blk;
+                    }
+                }
+                if (running) {
+                    t_prev = best;
+                    k_prev = bi;
+                    float2 av = vals[(size_t)bi * EGR_WAVE + lane];
+                    float alpha = av.x;
+                    uint32_t gid = f2u(av.y);
+                    float4 a0 = app[3 * gid], a1 = app[3 * gid + 1], a2 = app[3 * gid + 2];
+                    float next_T = T * (1.0f - alpha);       // :108
+                    float weight = T - next_T;               // :109
+                    c_rgb = c_rgb + mk3(a0.x, a0.y, a0.z) * weight;
+                    c_n = c_n + mk3(a0.w, a1.x, a1.y) * weight;
+                    c_f0 = c_f0 + mk3(a1.z, a1.w, a2.x) * weight;
+                    c_rough += a2.y * weight;
+                    c_depth += best * weight;
+                    T = next_T;
+                    nhits++;
+                    if (GRADS && recording)
+                        v.hit_arena[((size_t)cur_block * (EGR_HIT_BLOCK_ROWS + 1) + 1 + (it % EGR_HIT_BLOCK_ROWS)) * EGR_WAVE + lane] =
+                            make_float4(u2f(gid), best, alpha, T);
+                    if (T < transmittance_threshold || nhits >= EGR_MAX_COMPOSITED_PER_RAY) running = false; // :131-134, :55
+                }
+            }
+            if (GRADS) {
+                // arena exhausted: forward results stay exact, backward skips this task (status flag is raised)
+                if (lane == 0) v.task_last_block[(size_t)step * v.num_tasks + task] = recording ? last_block : 0xFFFFFFFFu;
+                S.st(SF(step, S_NHITS), u2f(recording ? nhits : 0u));
+            }
+        }
+        if (overflow && active) atomicOr(v.control + CW_STATUS, EGR_STATUS_CANDIDATE_OVERFLOW);
+
+        // ---- raw step results; R4/R5 (tail renormalisation, bounce sampling) run in k_step_epilogue (epilogue.hip),
+        // which is compiled without fma contraction (see the note there).
+        if (active) {
+            S.st3(SF(step, S_RGB), c_rgb), S.st(SF(step, S_DEPTH), c_depth), S.st3(SF(step, S_NORMAL), c_n);
+            S.st3(SF(step, S_F0), c_f0), S.st(SF(step, S_ROUGH), c_rough), S.st(SF(step, S_T), T), S.st(SF(step, S_TTOT), full_T);
+            if (step == 0) {
+                S.st3(F_RAY_O, ro), S.st3(F_RAY_D, rd);
+                S.st(F_SEED, u2f(seed));
+            }
+            v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)nhits;  // forward_pass.cu:140 (last step wins)
+            if (step == 0) v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)traversed;
+            else v.stats.num_traversed_per_pixel[tg.pixel_id] += (int32_t)traversed; // forward_pass.cu:46
+        }
+        w_rays += active ? 1u : 0u;
+        w_cand += active ? traversed : 0u;
+        w_comp += active ? nhits : 0u;
+    }
+    w_rays = wave_sum_u32(w_rays), w_cand = wave_sum_u32(w_cand), w_comp = wave_sum_u32(w_comp);
+    if (lane == 0) {
+        add64(v.control, CW_RAYS, w_rays), add64(v.control, CW_CAND, w_cand), add64(v.control, CW_COMP, w_comp);
+        if (step == 0) add64(v.control, CW_RAYS0, w_rays), add64(v.control, CW_COMP0, w_comp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward: one step, walked newest (farthest) hit first  (backward_pass.cu:3-222)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
+    const int lane = threadIdx.x;
+    const float exp_power = *v.cfg.exp_power;
+    const float eps_scale_grad = *v.cfg.eps_scale_grad;
+    const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
+    if (step > num_bounces) return;
+    const egr_gaussians &g = v.g;
+
+    for (;;) {
+        const uint32_t task = wave_next_task(v.control + CW_QUEUE0 + 3 + step);
+        if (task >= v.num_tasks) break;
+        uint32_t blk = v.task_last_block[(size_t)step * v.num_tasks + task];
+        if (blk == 0xFFFFFFFFu) continue;
+        const TaskGeom tg = task_geom(v, task, lane);
+        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
+        uint32_t steps_done = tg.inside ? f2u(S.ld(F_STEPS)) : 0u;
+        uint32_t nhits = (tg.inside && (uint32_t)step < steps_done) ? f2u(S.ld(SF(step, S_NHITS))) : 0u; // shaders.cu:157-158
+        const uint32_t max_hits = wave_max_u32(nhits);
+        if (max_hits == 0) continue;
+
+        // ---- B1: output gradients (backward_pass.cu:80-108); constant along the ray ----------------------
+        f3 dL_rgb = mk3(0, 0, 0), dL_n = mk3(0, 0, 0), dL_f0 = mk3(0, 0, 0);
+        float dL_depth = 0.0f, dL_rough = 0.0f;
+        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+        f3 rem_rgb = mk3(0, 0, 0), rem_n = mk3(0, 0, 0), rem_f0 = mk3(0, 0, 0);
+        float rem_depth = 0.0f, rem_rough = 0.0f, T_minus_Ttot = 0.0f;
+        if (nhits > 0) {
+            const uint32_t pid = tg.pixel_id;
+            const float third = 1.0f / 3.0f;
+            if (step == 0) {
+                f3 o_rgb = S.ld3(SF(0, S_RGB)), o_n = S.ld3(SF(0, S_NORMAL)), o_f0 = S.ld3(SF(0, S_F0));
+                float o_depth = S.ld(SF(0, S_DEPTH)), o_rough = S.ld(SF(0, S_ROUGH));
+                const float *td = v.fb.target_diffuse + 3 * (size_t)pid, *tn = v.fb.target_normal + 3 * (size_t)pid,
+                            *tf = v.fb.target_f0 + 3 * (size_t)pid;
+                dL_rgb = mk3(third * sign1(o_rgb.x - td[0]), third * sign1(o_rgb.y - td[1]), third * sign1(o_rgb.z - td[2])) * *v.cfg.loss_weight_diffuse;
+                dL_depth = sign1(o_depth - v.fb.target_depth[pid]) * *v.cfg.loss_weight_depth;
+                dL_n = mk3(third * sign1(o_n.x - tn[0]), third * sign1(o_n.y - tn[1]), third * sign1(o_n.z - tn[2])) * *v.cfg.loss_weight_normal;
+                dL_f0 = mk3(third * sign1(o_f0.x - tf[0]), third * sign1(o_f0.y - tf[1]), third * sign1(o_f0.z - tf[2])) * *v.cfg.loss_weight_f0;
+                dL_rough = sign1(o_rough - v.fb.target_roughness[pid]) * *v.cfg.loss_weight_roughness;
+                // primary ray is regenerated from the seed instead of being stored
+                uint32_t seed = tea4(pid, (uint32_t)*v.meta.total_num_calls);
+                ro = mk3(v.cam.origin[0], v.cam.origin[1], v.cam.origin[2]);
+                rd = primary_direction(v, tg.px, tg.py, *v.cfg.jitter_primary_rays != 0, seed);
+            } else {
+                f3 spec = mk3(0, 0, 0);
+                for (int j = 1; j < num_bounces + 1; j++)
+                    if ((uint32_t)j < steps_done) spec = spec + S.ld3(SF(j, S_RGB)); // unexecuted steps hold 0 upstream
+                const float *ts = v.fb.target_specular + 3 * (size_t)pid;
+                float down = powf(1.0f - S.ld(SF(step - 1, S_ROUGH)), EGR_ROUGHNESS_DOWNWEIGHT_GRAD_POWER); // :11-13
+                dL_rgb = (mk3(third * sign1(spec.x - ts[0]), third * sign1(spec.y - ts[1]), third * sign1(spec.z - ts[2])) *
+                          *v.cfg.loss_weight_specular) * down;
+                dL_rgb = dL_rgb * S.ld3(SF(step - 1, S_THR)); // :107, throughput of the previous step
+                ro = S.ld3(SF(step - 1, S_NEXT_O));
+                rd = S.ld3(SF(step - 1, S_NEXT_D));
+            }
+            rem_rgb = S.ld3(SF(step, S_REM_RGB)), rem_n = S.ld3(SF(step, S_REM_NORMAL)), rem_f0 = S.ld3(SF(step, S_REM_F0));
+            rem_depth = S.ld(SF(step, S_REM_DEPTH)), rem_rough = S.ld(SF(step, S_REM_ROUGH));
+            T_minus_Ttot = S.ld(SF(step, S_T)) - S.ld(SF(step, S_TTOT));
+        }
+
+        // ---- B2: per-hit chain -------------------------------------------------------------------------
+        f3 prev_rgb = mk3(0, 0, 0), w_rgb = mk3(0, 0, 0), prev_n = mk3(0, 0, 0), w_n = mk3(0, 0, 0), prev_f0 = mk3(0, 0, 0), w_f0 = mk3(0, 0, 0);
+        float prev_rough = 0, w_rough = 0, prev_depth = 0, w_depth = 0;
+        const uint32_t nblocks = (max_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
+        for (uint32_t b = nblocks; b-- > 0;) {
+            const float4 *rows = v.hit_arena + (size_t)blk * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE;
+            for (int row = EGR_HIT_BLOCK_ROWS - 1; row >= 0; row--) {
+                const uint32_t it = b * EGR_HIT_BLOCK_ROWS + (uint32_t)row;
+                if (it >= max_hits) continue;
+                if (it < nhits) {
+                    const float4 rec = rows[(size_t)(1 + row) * EGR_WAVE + lane];
+                    const uint32_t gid = f2u(rec.x);
+                    const float distance = rec.y, alpha = rec.z, transmittance = rec.w;
+                    const float4 a0 = v.app[3 * gid], a1 = v.app[3 * gid + 1], a2 = v.app[3 * gid + 2];
+                    const f3 g_rgb = mk3(a0.x, a0.y, a0.z);
+                    const float opacity = a2.z, scaling_factor = a2.w;
+                    // recompute the local hit exactly as the forward did
+                    f3 lo, ld, dhat, u;
+                    float t_unused;
+                    object_ray(v.inst_w, gid, ro, rd, lo, ld);
+                    closest_point(lo, ld, dhat, t_unused, u);
+                    const f3 local_hit = u * scaling_factor;
+                    const float sq_norm = dot(local_hit, local_hit);
+                    const float gaussval = eval_gaussian_sq(sq_norm, exp_power);
+
+                    const float weight = (float)((double)transmittance / (1.0 - (double)alpha) * (double)alpha); // :111
+                    // activation backward is evaluated on the ACTIVATED value (activations.cu:29,41-43) -> pass-through
+                    f3 d_rgb = (dL_rgb * weight);
+                    f3 d_n = dL_n * weight, d_f0 = dL_f0 * weight;
+                    float d_rough = dL_rough * weight;
+
+                    w_rgb = w_rgb + (g_rgb - prev_rgb) * transmittance; // :118-132
+                    prev_rgb = g_rgb;
+                    if (step == 0) {
+                        f3 g_n = mk3(a0.w, a1.x, a1.y), g_f0 = mk3(a1.z, a1.w, a2.x);
+                        w_n = w_n + (g_n - prev_n) * transmittance;
+                        prev_n = g_n;
+                        w_f0 = w_f0 + (g_f0 - prev_f0) * transmittance;
+                        prev_f0 = g_f0;
+                        w_rough += (a2.y - prev_rough) * transmittance;
+                        prev_rough = a2.y;
+                        w_depth += (distance - prev_depth) * transmittance;
+                        prev_depth = distance;
+                    }
+                    float dL_dalpha = 0.0f; // :134-148
+                    const float tmp1 = 1.0f / (1.0f - alpha);
+                    dL_dalpha += dot(w_rgb * tmp1, dL_rgb);
+                    dL_dalpha += dot(w_n * tmp1, dL_n);
+                    dL_dalpha += dot(w_f0 * tmp1, dL_f0);
+                    dL_dalpha += (w_rough * tmp1) * dL_rough;
+                    dL_dalpha += (w_depth * tmp1) * dL_depth;
+                    const float tmp2 = -(T_minus_Ttot / (1.0f - alpha));
+                    dL_dalpha += tmp2 * dot(rem_rgb, dL_rgb);
+                    dL_dalpha += tmp2 * dot(rem_n, dL_n);
+                    dL_dalpha += tmp2 * dot(rem_f0, dL_f0);
+                    dL_dalpha += tmp2 * (rem_rough * dL_rough);
+                    dL_dalpha += tmp2 * (rem_depth * dL_depth);
+
+                    float d_opacity = EGR_MAX_ALPHA * dL_dalpha * gaussval; // :151-152
+                    d_opacity = d_opacity * opacity * (1.0f - opacity);
+                    const float dL_dgaussval = EGR_MAX_ALPHA * dL_dalpha * opacity; // :155-158
+                    const float dL_dsq_norm = gaussval * pow_exp_m1(sq_norm, exp_power);
+                    const f3 dL_dx_local = (-local_hit * dL_dsq_norm) * dL_dgaussval;
+                    const float4 W0 = v.inst_w[3 * gid], W1 = v.inst_w[3 * gid + 1], W2 = v.inst_w[3 * gid + 2];
+                    const f3 dL_dx_world = mk3(dot(mk3(W0.x, W1.x, W2.x), dL_dx_local), dot(mk3(W0.y, W1.y, W2.y), dL_dx_local),
+                                               dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
+                    const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
+                    const f3 d_mean = -dL_dx_world;
+                    const f3 scaling = mk3(expf(g.scale[3 * gid]), expf(g.scale[3 * gid + 1]), expf(g.scale[3 * gid + 2]));
+                    const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
+                                       scaling.z * scaling_factor + eps_scale_grad);
+                    const float4 M0 = v.inst_m[3 * gid], M1 = v.inst_m[3 * gid + 1], M2 = v.inst_m[3 * gid + 2];
+                    const f3 rot_0 = mk3(M0.x, M0.y, M0.z) / den, rot_1 = mk3(M1.x, M1.y, M1.z) / den, rot_2 = mk3(M2.x, M2.y, M2.z) / den; // :178-180
+                    const f3 d_scale = (dl2w0 * rot_0 + dl2w1 * rot_1 + dl2w2 * rot_2) * scaling; // :181-182
+                    const f3 dr0 = dl2w0 * scaling, dr1 = dl2w1 * scaling, dr2 = dl2w2 * scaling; // :185-187
+                    const float4 qu = reinterpret_cast<const float4 *>(g.rotation)[gid];
+                    const float qn = sqrtf(qu.x * qu.x + qu.y * qu.y + qu.z * qu.z + qu.w * qu.w);
+                    const float r = qu.x / qn, x = qu.y / qn, y = qu.z / qn, z = qu.w / qn; // activations.cu:66-69
+                    const float dL_dr = 2.f * x * (dr2.y - dr1.z) + 2.f * y * (dr0.z - dr2.x) + 2.f * z * (dr1.x - dr0.y); // :194-205
+                    const float dL_dx = -4.f * x * (dr1.y + dr2.z) + 2.f * y * (dr0.y + dr1.x) + 2.f * z * (dr0.z + dr2.x) + 2.f * r * (dr2.y - dr1.z);
+                    const float dL_dy = 2.f * x * (dr0.y + dr1.x) - 4.f * y * (dr0.x + dr2.z) + 2.f * z * (dr1.z + dr2.y) + 2.f * r * (dr0.z - dr2.x);
+                    const float dL_dz = 2.f * x * (dr0.z + dr2.x) + 2.f * y * (dr1.z + dr2.y) - 4.f * z * (dr0.x + dr1.y) + 2.f * r * (dr1.x - dr0.y);
+                    const float dd = dL_dr * qu.x + dL_dx * qu.y + dL_dy * qu.z + dL_dz * qu.w; // activations.cu:71-73
+                    const float inv3 = 1.0f / (qn * qn * qn), inv1 = 1.0f / qn;
+
+                    // :210-220 flush (hardware fp32 atomics; order across rays is nondeterministic, as upstream)
+                    atomicAdd(&g.dL_dopacity[gid], d_opacity);
+                    atomicAdd(&g.dL_dscale[3 * gid], d_scale.x), atomicAdd(&g.dL_dscale[3 * gid + 1], d_scale.y), atomicAdd(&g.dL_dscale[3 * gid + 2], d_scale.z);
+                    atomicAdd(&g.dL_dmean[3 * gid], d_mean.x), atomicAdd(&g.dL_dmean[3 * gid + 1], d_mean.y), atomicAdd(&g.dL_dmean[3 * gid + 2], d_mean.z);
+                    atomicAdd(&g.dL_drotation[4 * gid], dd * -qu.x * inv3 + dL_dr * inv1);
+                    atomicAdd(&g.dL_drotation[4 * gid + 1], dd * -qu.y * inv3 + dL_dx * inv1);
+                    atomicAdd(&g.dL_drotation[4 * gid + 2], dd * -qu.z * inv3 + dL_dy * inv1);
+                    atomicAdd(&g.dL_drotation[4 * gid + 3], dd * -qu.w * inv3 + dL_dz * inv1);
+                    atomicAdd(&g.dL_drgb[3 * gid], d_rgb.x), atomicAdd(&g.dL_drgb[3 * gid + 1], d_rgb.y), atomicAdd(&g.dL_drgb[3 * gid + 2], d_rgb.z);
+                    if (step == 0) {
+                        atomicAdd(&g.dL_dnormal[3 * gid], d_n.x), atomicAdd(&g.dL_dnormal[3 * gid + 1], d_n.y), atomicAdd(&g.dL_dnormal[3 * gid + 2], d_n.z);
+                        atomicAdd(&g.dL_df0[3 * gid], d_f0.x), atomicAdd(&g.dL_df0[3 * gid + 1], d_f0.y), atomicAdd(&g.dL_df0[3 * gid + 2], d_f0.z);
+                        atomicAdd(&g.dL_droughness[gid], d_rough);
+                    }
+                    atomicAdd(&g.total_weight[gid], weight);
+                }
+            }
+            blk = f2u(rows[0].x); // header: previous (older) block of this task
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// R6: output write / accumulation (shaders.cu:163-169, framebuffer.h:104-143); no-grad launches only
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EGR_WAVE) k_finish(DeviceView v) {
+    const int lane = threadIdx.x;
+    const bool accumulate = *v.cfg.accumulate_samples != 0;
+    const float cnt = accumulate ? (float)(*v.fb.accumulated_sample_count + 1) : 1.0f;
+    const size_t P = v.num_pixels;
+    for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
+        const TaskGeom tg = task_geom(v, task, lane);
+        if (!tg.inside) continue;
+        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
+        const uint32_t steps = f2u(S.ld(F_STEPS));
+        f3 final = mk3(0, 0, 0);
+        for (int s = 0; s < EGR_NSTEPS; s++) {
+            const bool done = (uint32_t)s < steps;
+            f3 rgb = done ? S.ld3(SF(s, S_RGB)) : mk3(0, 0, 0), n = done ? S.ld3(SF(s, S_NORMAL)) : mk3(0, 0, 0);
+            f3 f0 = done ? S.ld3(SF(s, S_F0)) : mk3(0, 0, 0);
+            float depth = done ? S.ld(SF(s, S_DEPTH)) : 0.0f, rough = done ? S.ld(SF(s, S_ROUGH)) : 0.0f;
+            float T = done ? S.ld(SF(s, S_T)) : 1.0f, Ttot = done ? S.ld(SF(s, S_TTOT)) : 1.0f;
+            f3 no = done ? S.ld3(SF(s, S_NEXT_O)) : mk3(0, 0, 0), nd = done ? S.ld3(SF(s, S_NEXT_D)) : mk3(0, 0, 0);
+            const size_t q = tg.pixel_id + P * (size_t)s;
+            if (accumulate) { // framebuffer.h:104-128
+#define EGR_ACC3(buf, val) { float *a_ = v.fb.buf + 3 * q; a_[0] += val.x, a_[1] += val.y, a_[2] += val.z; val = div_s(mk3(a_[0], a_[1], a_[2]), cnt); }
+#define EGR_ACC1(buf, val) { float *a_ = v.fb.buf + q; a_[0] += val; val = a_[0] / cnt; }
+                EGR_ACC3(accumulated_rgb, rgb) EGR_ACC1(accumulated_transmittance, T) EGR_ACC1(accumulated_total_transmittance, Ttot)
+                EGR_ACC1(accumulated_depth, depth) EGR_ACC3(accumulated_normal, n) EGR_ACC3(accumulated_f0, f0) EGR_ACC1(accumulated_roughness, rough)
+#undef EGR_ACC3
+#undef EGR_ACC1
+            }
+            final = final + rgb;
+            float *o;
+            o = v.fb.output_rgb + 3 * q, o[0] = rgb.x, o[1] = rgb.y, o[2] = rgb.z;
+            o = v.fb.output_normal + 3 * q, o[0] = n.x, o[1] = n.y, o[2] = n.z;
+            o = v.fb.output_f0 + 3 * q, o[0] = f0.x, o[1] = f0.y, o[2] = f0.z;
+            o = v.fb.output_ray_origin + 3 * q, o[0] = no.x, o[1] = no.y, o[2] = no.z;
+            o = v.fb.output_ray_direction + 3 * q, o[0] = nd.x, o[1] = nd.y, o[2] = nd.z;
+            v.fb.output_depth[q] = depth, v.fb.output_roughness[q] = rough;
+            v.fb.output_transmittance[q] = T, v.fb.output_total_transmittance[q] = Ttot;
+        }
+        float *o = v.fb.output_final + 3 * (size_t)tg.pixel_id;
+        o[0] = final.x, o[1] = final.y, o[2] = final.z;
+    }
+}
+
+__global__ void k_copy3(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+template <class T> void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+} // namespace
+
+void egr_launch_step_epilogue(const DeviceView &v, int step, bool grads, hipStream_t s); // epilogue.hip
+
+uint32_t egr_num_tasks_for_rank(const egr_context *c) {
+    uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
+    uint32_t M = mtx * mty;
+    if ((uint32_t)c->rank >= M) return 0;
+    return 4u * ((M - (uint32_t)c->rank + (uint32_t)c->world - 1) / (uint32_t)c->world);
+}
+
+void egr_trace_free(egr_context *c) {
+    dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
+    if (c->control_host) (void)hipHostFree(c->control_host);
+    c->control_host = nullptr;
+}
+
+void egr_trace_alloc(egr_context *c) {
+    uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
+    c->num_tasks_total = 4u * mtx * mty;
+    hipDeviceProp_t prop;
+    EGR_HIP(hipGetDeviceProperties(&prop, c->device));
+    int per_cu_g = 0, per_cu_n = 0;
+    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, k_forward<true>, EGR_WAVE, 0));
+    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_n, k_forward<false>, EGR_WAVE, 0));
+    int per_cu = std::max(1, std::min(32, std::max(per_cu_g, per_cu_n)));
+    uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+    c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
+    // forward budget: the reference's ppll_forward_size entries x 36 B, spent on (key 4 B + value 8 B) x 64 lanes x cap per slot
+    double fwd_bytes = (double)c->fwd_capacity * 36.0;
+    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * EGR_WAVE * 12.0));
+    c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384);
+    EGR_HIP(hipMalloc((void **)&c->cand_keys, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
+    EGR_HIP(hipMalloc((void **)&c->cand_vals, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
+    double bwd_bytes = (double)c->bwd_capacity * 36.0;
+    uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
+    c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
+    EGR_HIP(hipMalloc((void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
+    EGR_HIP(hipMalloc((void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * sizeof(uint32_t)));
+    c->state_stride = c->num_tasks_total * EGR_WAVE;
+    EGR_HIP(hipMalloc((void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
+    EGR_HIP(hipMemset(c->state, 0, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
+    EGR_HIP(hipMalloc((void **)&c->control, CW_COUNT * sizeof(uint32_t)));
+    EGR_HIP(hipMemset(c->control, 0, CW_COUNT * sizeof(uint32_t)));
+    EGR_HIP(hipHostMalloc((void **)&c->control_host, CW_COUNT * sizeof(uint32_t)));
+}
+
+DeviceView egr_make_view(const egr_context *c) {
+    DeviceView v{};
+    v.width = c->width, v.height = c->height;
+    v.tiles_x = (c->width + EGR_TILE - 1) / EGR_TILE, v.tiles_y = (c->height + EGR_TILE - 1) / EGR_TILE;
+    v.num_pixels = (uint32_t)c->width * (uint32_t)c->height;
+    v.n = c->g.count;
+    v.num_nodes = c->n_built ? 2 * c->n_built - 1 : 0;
+    v.rank = c->rank, v.world = c->world;
+    v.num_tasks = egr_num_tasks_for_rank(c);
+    v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
+    v.nodes = c->nodes, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
+    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
+    v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
+    v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
+    return v;
+}
+
+void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
+    DeviceView v = egr_make_view(c);
+    const dim3 grid(std::max(1u, std::min(c->num_slots, std::max(1u, v.num_tasks)))), block(EGR_WAVE);
+    egr_stamp_begin(c, "prologue+live", s);
+    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
+    EGR_HIP(hipMemsetAsync(c->stats.num_accumulated_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s)); // stats.h:25-28
+    EGR_HIP(hipMemsetAsync(c->stats.num_traversed_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s));
+    if (v.n) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v);
+    egr_stamp_end(c, s);
+    static const char *fn[3] = {"forward_step0", "forward_step1", "forward_step2"};
+    static const char *bn[3] = {"backward_step0", "backward_step1", "backward_step2"};
+    if (v.num_tasks) {
+        for (int step = 0; step < EGR_NSTEPS; step++) {
+            egr_stamp_begin(c, fn[step], s);
+            if (grads) hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, v, step);
+            else hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, v, step);
+            egr_launch_step_epilogue(v, step, grads, s);
+            egr_stamp_end(c, s);
+        }
+        if (grads) {
+            for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
+                egr_stamp_begin(c, bn[step], s);
+                hipLaunchKernelGGL(k_backward, grid, block, 0, s, v, step);
+                egr_stamp_end(c, s);
+            }
+        } else {
+            egr_stamp_begin(c, "write_outputs", s);
+            hipLaunchKernelGGL(k_finish, dim3(std::min(v.num_tasks, 65535u)), block, 0, s, v);
+            egr_stamp_end(c, s);
+        }
+    }
+    hipLaunchKernelGGL(k_epilogue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
+    EGR_HIP(hipMemcpyAsync(c->control_host, c->control, CW_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+}
+
+void egr_copy_final_to_denoised(egr_context *c, hipStream_t s) {
+    size_t n = (size_t)c->width * c->height * 3;
+    hipLaunchKernelGGL(k_copy3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->fb.output_final, c->fb.output_denoised, n);
+}

@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's L3 caller:
+editable_gauss_refl/renderer/gaussian_raytracer.py:10-151 (`GaussianRaytracer`) and
+editable_gauss_refl/renderer/gaussian_renderer.py:21-92 (`render`).
+
+Same call sequence, attribute names and tensor conventions, so a reference `GaussianModel` / `Camera` can be
+passed unchanged: pose conversion R_blender = -R with column 0 re-negated, set_pose(camera_center, R_blender),
+fov = FoVy, ZNEAR/ZFAR env overrides, export order, targets CHW -> HWC, zero targets when absent, update_bvh iff
+grad mode or forced, raytrace, optional denoise, gradient import by add_.
+
+Additions for the MI355X build: `rank` / `world_size` (image-tile partition) and
+`all_reduce_grads()` which sums the flat [22N] gradient buffer over ranks with ONE RCCL all-reduce.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import make_raytracer
+
+
+class GaussianParams:
+    """Minimal stand-in for the parts of scene/gaussian_model.py:31 the tracer reads (raw, pre-activation tensors
+    with the reference's attribute names). `cfg` carries the nine values pushed into the native config."""
+
+    def __init__(self, g, device="cuda", cfg=None):
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=device).contiguous()
+        self._xyz, self._opacity, self._scaling, self._rotation = t(g["mean"]), t(g["opacity"]), t(g["scale"]), t(g["rotation"])
+        self._diffuse, self._normal, self._roughness, self._f0 = t(g["rgb"]), t(g["normal"]), t(g["roughness"]), t(g["f0"])
+        for p in self.parameters():
+            p.grad = torch.zeros_like(p)
+        self.cfg = cfg or SimpleNamespace(loss_weight_diffuse=5.0, loss_weight_specular=3.0, loss_weight_normal=2.5, loss_weight_depth=2.5,
+                                          loss_weight_f0=1.0, loss_weight_roughness=1.0, transmittance_threshold=0.01, alpha_threshold=0.005,
+                                          exp_power=3)
+
+    def parameters(self):
+        return [self._xyz, self._opacity, self._scaling, self._rotation, self._diffuse, self._normal, self._roughness, self._f0]
+
+    # getters read by _export_param_values (gaussian_raytracer.py:41-50); an EditableGaussianModel overrides these
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    _get_scaling = property(lambda s: s._scaling)
+    _get_rotation = property(lambda s: s._rotation)
+    get_xyz = property(lambda s: s._xyz)
+    get_diffuse = property(lambda s: s._diffuse)
+    get_normal = property(lambda s: s._normal)
+    get_roughness = property(lambda s: s._roughness)
+    get_f0 = property(lambda s: s._f0)
+
+
+class GaussianRaytracer:
+    def __init__(self, pc, image_width: int, image_height: int, ppll_forward_size=None, ppll_backward_size=None, rank=0, world_size=1):
+        self.image_width, self.image_height = image_width, image_height
+        kw = {}
+        if ppll_forward_size is not None:
+            kw["ppll_forward_size"] = int(ppll_forward_size)
+        if ppll_backward_size is not None:
+            kw["ppll_backward_size"] = int(ppll_backward_size)
+        self.cuda_module = make_raytracer(image_width, image_height, pc.get_scaling.shape[0], **kw)
+        self.rank, self.world_size = rank, world_size
+        if world_size > 1:
+            self.cuda_module.set_partition(rank, world_size)
+        config = self.cuda_module.get_config()  # gaussian_raytracer.py:16-25
+        config.loss_weight_diffuse.fill_(pc.cfg.loss_weight_diffuse)
+        config.loss_weight_specular.fill_(pc.cfg.loss_weight_specular)
+        config.loss_weight_normal.fill_(pc.cfg.loss_weight_normal)
+        config.loss_weight_depth.fill_(pc.cfg.loss_weight_depth)
+        config.loss_weight_f0.fill_(pc.cfg.loss_weight_f0)
+        config.loss_weight_roughness.fill_(pc.cfg.loss_weight_roughness)
+        config.transmittance_threshold.fill_(pc.cfg.transmittance_threshold)
+        config.alpha_threshold.fill_(pc.cfg.alpha_threshold)
+        config.exp_power.fill_(pc.cfg.exp_power)
+        self.pc = pc
+        self._export_param_values()
+        self.cuda_module.rebuild_bvh()
+
+    @torch.no_grad()
+    def rebuild_bvh(self):  # gaussian_raytracer.py:33-38
+        self.cuda_module.resize(self.pc._xyz.shape[0])
+        self._export_param_values()
+        self.cuda_module.rebuild_bvh()
+
+    @torch.no_grad()
+    def _export_param_values(self):  # gaussian_raytracer.py:41-50 (same order)
+        g = self.cuda_module.get_gaussians()
+        g.scale.copy_(self.pc._get_scaling)
+        g.rotation.copy_(self.pc._get_rotation)
+        g.mean.copy_(self.pc.get_xyz)
+        g.opacity.copy_(self.pc._opacity)
+        g.rgb.copy_(self.pc.get_diffuse)
+        g.normal.copy_(self.pc.get_normal)
+        g.roughness.copy_(self.pc.get_roughness)
+        g.f0.copy_(self.pc.get_f0)
+
+    @torch.no_grad()
+    def _import_param_gradients(self):  # gaussian_raytracer.py:53-62
+        g = self.cuda_module.get_gaussians()
+        self.pc._xyz.grad.add_(g.mean.grad)
+        self.pc._opacity.grad.add_(g.opacity.grad)
+        self.pc._scaling.grad.add_(g.scale.grad)
+        self.pc._rotation.grad.add_(g.rotation.grad)
+        self.pc._diffuse.grad.add_(g.rgb.grad)
+        self.pc._normal.grad.add_(g.normal.grad)
+        self.pc._roughness.grad.add_(g.roughness.grad)
+        self.pc._f0.grad.add_(g.f0.grad)
+
+    def zero_grad(self):  # gaussian_raytracer.py:64-73 (one fill of the flat buffer == the eight zero_() upstream + total_weight kept)
+        g = self.cuda_module.get_gaussians()
+        for t in (g.rgb, g.opacity, g.scale, g.rotation, g.mean, g.normal, g.roughness, g.f0):
+            t.grad.zero_()
+
+    @torch.no_grad()
+    def all_reduce_grads(self):
+        """Multi-GPU exchange step: sum the per-Gaussian gradients + total_weight of all ranks with a
+        single all-reduce over the contiguous [22N] buffer (88 MB at N=1M). No-op for world_size == 1."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.cuda_module.get_gaussians().grad_flat, op=dist.ReduceOp.SUM)
+
+    @staticmethod
+    def blender_rotation(R):
+        """gaussian_raytracer.py:95-97: R_c2w_blender = -R; R_c2w_blender[:, 0] *= -1."""
+        Rb = -R
+        Rb[:, 0] = -Rb[:, 0]
+        return Rb
+
+    def __call__(self, viewpoint_camera, target=None, target_diffuse=None, target_specular=None, target_depth=None, target_normal=None,
+                 target_roughness=None, target_f0=None, force_update_bvh=False, denoise=False, znear=0.01, zfar=999.9):
+        with torch.no_grad():
+            R = torch.from_numpy(viewpoint_camera.R).cuda().float() if isinstance(viewpoint_camera.R, np.ndarray) else viewpoint_camera.R.cuda()
+            R_c2w_blender = self.blender_rotation(R.clone())
+            camera = self.cuda_module.get_camera()
+            camera.znear.fill_(float(os.getenv("ZNEAR", znear)))
+            camera.zfar.fill_(float(os.getenv("ZFAR", zfar)))
+            camera.vertical_fov_radians.fill_(float(viewpoint_camera.FoVy))
+            camera.set_pose(viewpoint_camera.camera_center.contiguous(), R_c2w_blender.contiguous())
+            self._export_param_values()
+            framebuffer = self.cuda_module.get_framebuffer()
+            for name, val in (("target_diffuse", target_diffuse), ("target_specular", target_specular), ("target_depth", target_depth),
+                              ("target_normal", target_normal), ("target_roughness", target_roughness), ("target_f0", target_f0)):
+                buf = getattr(framebuffer, name)
+                if val is not None:
+                    buf.copy_(val.moveaxis(0, -1))  # CHW -> HWC (gaussian_raytracer.py:109-137)
+                else:
+                    buf.zero_()
+        if torch.is_grad_enabled() or force_update_bvh:
+            self.cuda_module.update_bvh()
+        self.cuda_module.raytrace()
+        if denoise:
+            self.cuda_module.denoise()
+        if torch.is_grad_enabled():
+            self.all_reduce_grads()
+            self._import_param_gradients()
+        return {"render": framebuffer.output_rgb.clone()}
+
+
+def render(camera, raytracer: GaussianRaytracer, targets_available=True, force_update_bvh=False, denoise=False, znear=0.01, zfar=999.9):
+    """gaussian_renderer.py:21-92: returns CHW clones rgb[3,3,H,W], final[1,3,H,W], depth/normal/roughness/f0."""
+    do_backprop = torch.is_grad_enabled()
+    names = ("original_image", "diffuse_image", "specular_image", "normal_image", "f0_image", "roughness_image", "depth_image")
+    tg = {n: (getattr(camera, n, None) if targets_available else None) for n in names}
+    with torch.set_grad_enabled(do_backprop):
+        raytracer(camera, target=tg["original_image"], target_diffuse=tg["diffuse_image"], target_specular=tg["specular_image"],
+                  target_depth=tg["depth_image"], target_normal=tg["normal_image"], target_roughness=tg["roughness_image"],
+                  target_f0=tg["f0_image"], force_update_bvh=force_update_bvh, denoise=denoise, znear=znear, zfar=zfar)
+    fb = raytracer.cuda_module.get_framebuffer()
+    cl = lambda t: t.clone().detach().moveaxis(-1, 1)
+    return SimpleNamespace(rgb=cl(fb.output_rgb), final=cl(fb.output_denoised) if denoise else cl(fb.output_final), depth=cl(fb.output_depth),
+                           normal=cl(fb.output_normal), roughness=cl(fb.output_roughness), f0=cl(fb.output_f0), target=tg["original_image"],
+                           target_diffuse=tg["diffuse_image"], target_specular=tg["specular_image"], target_depth=tg["depth_image"],
+                           target_normal=tg["normal_image"], target_roughness=tg["roughness_image"], target_f0=tg["f0_image"])
+
+
+def camera_from_c2w(origin, c2w_blender, fov, **images):
+    """Builds a duck-typed reference `Camera` (scene/cameras.py:22) whose .R reproduces `c2w_blender` after the
+    caller-side conversion above (R = blender rotation with the inverse flip applied)."""
+    Rb = torch.as_tensor(np.asarray(c2w_blender), dtype=torch.float32).clone()
+    R = Rb.clone()
+    R[:, 0] = -R[:, 0]
+    R = -R
+    cam = SimpleNamespace(R=R.cuda(), FoVy=float(fov), camera_center=torch.as_tensor(np.asarray(origin), dtype=torch.float32).cuda())
+    for k, v in images.items():
+        setattr(cam, k, v)
+    return cam

@@ -1,0 +1,173 @@
+/*
+ * egr_raytracer.h -- C ABI of the MI355X-native differentiable Gaussian ray tracer (libegr_hip.so).
+ *
+ * Drop-in boundary for the hot path of graphdeco-inria/editable-gaussian-reflections:
+ * editable_gauss_refl/cuda (OptiX/CUDA). The reference exposes this path as TorchScript custom classes
+ * (TORCH_LIBRARY(raytracer, m), cuda/csrc/raytracer.cpp:208-218); every entry point below replaces one
+ * method of that `Raytracer` class and takes exactly the raw device pointers its `reify()` structs hold.
+ * No torch types cross this boundary. The thin TORCH_LIBRARY shim that re-exports these functions under
+ * the reference's class names lives in editable-gaussian-reflections_amd/csrc/torch_binding.cpp; the
+ * reference-side binding is shown in INTEGRATION.md.
+ *
+ * All pointers are DEVICE pointers (HIP, gfx950) unless stated otherwise. All arithmetic is fp32.
+ * Functions return 0 on success, non-zero on failure; egr_last_error() gives the message. Nothing here
+ * synchronises the stream unless documented. Not thread-safe per context (the reference is not either:
+ * train.py:214-215 serialises callers with a lock).
+ *
+ * Paths in comments are relative to /root/reference/editable_gauss_refl/cuda/csrc/.
+ */
+#ifndef EGR_RAYTRACER_H
+#define EGR_RAYTRACER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGR_MAX_BOUNCES 2                       /* flags.h:4  */
+#define EGR_NUM_STEPS (EGR_MAX_BOUNCES + 1)
+#define EGR_MAX_ALPHA 0.9999f                   /* flags.h:7  */
+#define EGR_ROUGHNESS_DOWNWEIGHT_GRAD 1         /* flags.h:11 */
+#define EGR_ROUGHNESS_DOWNWEIGHT_GRAD_POWER 3.0f /* flags.h:12 */
+#define EGR_MAX_COMPOSITED_PER_RAY (16 * 99)    /* BUFFER_SIZE * MAX_ITERATIONS, flags.h:15-16 */
+#define EGR_PPLL_NULL_PTR (2u << 29)            /* core/per_pixel_linked_list.h:4 */
+
+typedef struct egr_context egr_context; /* replaces struct Raytracer (raytracer.cpp:24-79) */
+
+/* core/gaussians.h:3-25 -- raw (pre-activation) parameters, row-major [count, k], and their gradients */
+typedef struct egr_gaussians {
+    uint32_t count;
+    const float *rgb;       /* [N,3] relu            */
+    const float *normal;    /* [N,3] identity        */
+    const float *f0;        /* [N,3] clip01          */
+    const float *roughness; /* [N,1] clip01          */
+    const float *opacity;   /* [N,1] sigmoid         */
+    const float *scale;     /* [N,3] exp             */
+    const float *mean;      /* [N,3] identity        */
+    const float *rotation;  /* [N,4] normalise (r,x,y,z) */
+    float *dL_drgb, *dL_dnormal, *dL_df0, *dL_droughness, *dL_dopacity, *dL_dscale, *dL_dmean, *dL_drotation;
+    float *total_weight;    /* [N,1] */
+} egr_gaussians;
+
+/* core/config.h:5-26 -- device-resident scalars, read by pointer inside the kernels (Python mutates them in place) */
+typedef struct egr_config {
+    const float *exp_power, *alpha_threshold, *transmittance_threshold;
+    const uint8_t *accumulate_samples, *jitter_primary_rays; /* torch bool */
+    const int32_t *num_bounces;
+    const float *global_scale_factor;
+    const float *loss_weight_diffuse, *loss_weight_specular, *loss_weight_depth, *loss_weight_normal, *loss_weight_f0,
+        *loss_weight_roughness;
+    const float *eps_forward_normalization, *eps_scale_grad, *eps_ray_surface_offset, *eps_min_roughness;
+    const float *reflection_invalid_normal_threshold, *backfacing_invalid_normal_threshold, *backfacing_max_dist;
+} egr_config;
+
+/* core/camera.h:8-15 */
+typedef struct egr_camera {
+    const float *origin;               /* [3]   */
+    const float *vertical_fov_radians; /* [1]   */
+    const float *rotation_c2w;         /* [3,3] */
+    const float *rotation_w2c;         /* [3,3] = c2w^T (camera.h:67) */
+    const float *znear, *zfar;         /* [1]   */
+} egr_camera;
+
+/* core/framebuffer.h:72-102 -- outputs [3,H,W,c] indexed pixel_id + H*W*step (:132), final/denoised [1,H,W,3] */
+typedef struct egr_framebuffer {
+    float *output_rgb, *output_depth, *output_normal, *output_f0, *output_roughness, *output_transmittance,
+        *output_total_transmittance, *output_ray_origin, *output_ray_direction, *output_final, *output_denoised;
+    float *accumulated_rgb, *accumulated_transmittance, *accumulated_total_transmittance, *accumulated_depth,
+        *accumulated_normal, *accumulated_f0, *accumulated_roughness;
+    int32_t *accumulated_sample_count; /* [1] */
+    const float *target_diffuse, *target_specular, *target_depth, *target_normal, *target_f0, *target_roughness;
+} egr_framebuffer;
+
+/* core/metadata.h:3-7 */
+typedef struct egr_metadata {
+    uint8_t *grads_enabled;    /* [1] torch bool, written by egr_raytrace from its argument (metadata.h:29) */
+    int32_t *total_num_calls;  /* [1] incremented by egr_raytrace before the launch (metadata.h:30)        */
+    int32_t *random_seeds;     /* [H,W,1] final per-pixel RNG state (shaders.cu:172)                        */
+} egr_metadata;
+
+/* core/stats.h:3-6 */
+typedef struct egr_stats {
+    int32_t *num_accumulated_per_pixel; /* [H,W] composited hits of the LAST executed step (forward_pass.cu:140) */
+    int32_t *num_traversed_per_pixel;   /* [H,W] intersection-program invocations, all steps (forward_pass.cu:46) */
+} egr_stats;
+
+/* Whole-launch work counters (not in the reference; used for the roofline's algorithmic bytes). */
+typedef struct egr_counters {
+    uint64_t rays;            /* sum over pixels of executed steps                     */
+    uint64_t rays_step0;      /* primary rays                                          */
+    uint64_t candidates;      /* sum of cube-overlap candidates (Hc)                   */
+    uint64_t composited;      /* sum of composited hits over all steps (Kc)            */
+    uint64_t composited_step0;
+    uint32_t status;          /* EGR_STATUS_* bit mask of the last launch              */
+    uint32_t bvh_depth;
+} egr_counters;
+
+#define EGR_STATUS_OK 0u
+#define EGR_STATUS_CANDIDATE_OVERFLOW 1u /* a ray met more candidates than the forward capacity allows (dropped) */
+#define EGR_STATUS_HIT_ARENA_OVERFLOW 2u /* composited-hit arena (backward capacity) exhausted; gradients partial */
+
+/* Raytracer::Raytracer(width, height, num_gaussians, ppll_forward_size, ppll_backward_size) (raytracer.cpp:45-79).
+ * The two sizes are entry counts of the reference's per-pixel linked lists (36 B per entry,
+ * per_pixel_linked_list.h:6-16); this implementation spends the same byte budgets on its candidate scratch and
+ * its composited-hit arena. device = HIP device ordinal the buffers live on. */
+int egr_create(egr_context **ctx, int device, int width, int height, int64_t ppll_forward_size, int64_t ppll_backward_size);
+void egr_destroy(egr_context *ctx);
+
+/* params_on_host.{camera,config,framebuffer,metadata,stats} = holder->reify() (raytracer.cpp:61-68) */
+int egr_bind(egr_context *ctx, const egr_camera *camera, const egr_config *config, const egr_framebuffer *framebuffer,
+             const egr_metadata *metadata, const egr_stats *stats);
+
+/* Raytracer::resize re-reify + upload of Params.gaussians (raytracer.cpp:112-120) */
+int egr_set_gaussians(egr_context *ctx, const egr_gaussians *gaussians);
+
+/* Raytracer::rebuild_bvh (raytracer.cpp:102-110; optix/bvh_wrapper.h:24-30,118-157): instance transforms from
+ * the current parameters + full LBVH build. Synchronises the stream (the reference's build also does). */
+int egr_rebuild_bvh(egr_context *ctx, void *hip_stream);
+
+/* Raytracer::update_bvh (raytracer.cpp:100; optix/bvh_wrapper.h:32-59): re-snapshot instance transforms and
+ * refit the existing tree. Asynchronous; reads alpha_threshold/exp_power/global_scale_factor on the device
+ * (the reference does three blocking .item() reads, bvh_wrapper.h:38-40). */
+int egr_update_bvh(egr_context *ctx, void *hip_stream);
+
+/* Raytracer::raytrace (raytracer.cpp:81-94): metadata update, stats reset, one launch of the whole
+ * forward (+ backward when grads_enabled) path = __raygen__rg (shaders.cu:77-173), then
+ * accumulated_sample_count += 1 when accumulate_samples. grads_enabled is what
+ * torch::autograd::GradMode::is_enabled() returned in the caller (metadata.h:29). Asynchronous. */
+int egr_raytrace(egr_context *ctx, int grads_enabled, void *hip_stream);
+
+/* Raytracer::denoise (raytracer.cpp:96; optix/denoiser_wrapper.h). The OptiX AI denoiser is a closed network and
+ * is out of scope; this stand-in copies output_final into output_denoised so callers keep working. */
+int egr_denoise(egr_context *ctx, void *hip_stream);
+
+/* Multi-GPU image partition (not in the reference): this context only traces the 16x16-pixel
+ * macro tiles with (tile_index % world_size) == rank; default rank 0 of 1 = whole image. */
+int egr_set_partition(egr_context *ctx, int rank, int world_size);
+
+/* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace. */
+int egr_get_counters(egr_context *ctx, egr_counters *out, void *hip_stream);
+
+/* Wall-clock of the last egr_raytrace / egr_update_bvh on the GPU (HIP events recorded on the launch stream
+ * when timing is enabled). Returns milliseconds, <0 if not available. Synchronises on the end event. */
+int egr_enable_timing(egr_context *ctx, int enable);
+float egr_last_raytrace_ms(egr_context *ctx);
+float egr_last_update_bvh_ms(egr_context *ctx);
+/* duration of the individual kernels of the last egr_raytrace, in launch order; returns count written */
+int egr_last_kernel_ms(egr_context *ctx, float *ms, const char **names, int max_entries);
+
+/* Copies the snapshot instance records for parity tests: M[N*12], W[N*12] (3x4 row-major), aabb[N*6]
+ * (lo xyz, hi xyz; invisible instances have lo > hi). Host pointers; synchronises. */
+int egr_debug_get_instances(egr_context *ctx, float *M, float *W, float *aabb, void *hip_stream);
+/* BVH self-check: every leaf box equals its instance box, every internal box is the union of its children,
+ * every visible instance is reachable exactly once. Returns 0 if consistent. Host-side; synchronises. */
+int egr_debug_check_bvh(egr_context *ctx, void *hip_stream);
+
+const char *egr_last_error(egr_context *ctx);
+const char *egr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGR_RAYTRACER_H */
