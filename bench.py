@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mrays/s forward+backward @1080p, 1M Gaussians (BASELINE.json metric) on MI355X.
+
+One "step" = one training-iteration pass of the hot path behind the reference's own caller
+(GaussianRaytracer.__call__ in grad mode: parameter export, target upload, update_bvh (instance snapshot +
+LBVH refit), raytrace (forward + in-kernel loss gradient + backward), gradient all-reduce over ranks, gradient
+import). A "ray" = one (pixel, bounce-step) traversal; rays/step come from the kernels' own counters.
+
+  python bench.py                       # 1 GPU, defaults finish in a few minutes
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the image is split into 16x16-pixel tiles dealt round-robin to the ranks (the scene and the BVH are
+replicated), gradients are summed with ONE RCCL all-reduce of the flat [22N] buffer -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--gaussians", type=int, default=1_000_000)
+    p.add_argument("--variant", default="trained", choices=["trained", "init"])
+    p.add_argument("--bounces", type=int, default=2)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", default="480x270")
+    p.add_argument("--profile-steps", type=int, default=5, help="extra untimed launches with per-kernel HIP events")
+    p.add_argument("--forward-only", action="store_true", help="config B: no-grad render instead of a training iteration")
+    return p.parse_args()
+
+
+def algorithmic_bytes(kind, step, rays, hc, kc, pixels):
+    """SURVEY.md 8d per-ray algorithmic bytes: forward 44*Hc (mean 12 + rotation 16 + scale 12 + opacity 4) + 40*Kc
+    (rgb, normal, f0, roughness) [+76 B outputs in no-grad mode only]; backward step 0: 260*Kc, step>0: 176*Kc
+    (parameter re-reads + 22/15 float atomics at 8 B each); +56 B/pixel targets in grad mode (charged to backward 0)."""
+    if kind == "forward":
+        return 44.0 * hc + 40.0 * kc
+    if kind == "forward_nograd":
+        return 44.0 * hc + 40.0 * kc + 76.0 * rays
+    if kind == "backward":
+        return (260.0 if step == 0 else 176.0) * kc + (56.0 * pixels if step == 0 else 0.0)
+    raise ValueError(kind)
+
+
+def main():
+    a = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic")
+    ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
+
+    W, H, N = a.width, a.height, a.gaussians
+    g = syn.make_scene(N, a.variant, seed=0)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    pc = ren.GaussianParams(g)
+    # capacities: same meaning as the reference's ppll sizes (entries of 36 B); its own test uses 300M/200M at 1536x1024
+    rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000, rank=rank, world_size=world)
+    m = rt.cuda_module
+    m.get_config().num_bounces.fill_(a.bounces)
+    images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()}
+    camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **images)
+
+    def one_step():
+        if a.forward_only:
+            with torch.no_grad():
+                rt(camera)
+        else:
+            rt.zero_grad()
+            rt(camera, target_diffuse=images["diffuse_image"], target_specular=images["specular_image"], target_depth=images["depth_image"],
+               target_normal=images["normal_image"], target_roughness=images["roughness_image"], target_f0=images["f0_image"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    m.reset_lifetime_counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    c = m.get_counters()
+    status = c[11]
+    life_rays = c[9]
+    tt = torch.tensor([dt, float(life_rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, total_rays = float(tmax[0]), float(tsum[1])
+    else:
+        total_rays = float(life_rays)
+    ms_per_step = dt / a.steps * 1e3
+    value = total_rays / dt / 1e6
+
+    # ---- per-kernel timing pass (HIP events on the launch stream, untimed region) -> roofline of the dominant kernel
+    roof = None
+    kern = {}
+    if rank == 0:
+        m.enable_timing(True)
+        acc = {}
+        for _ in range(a.profile_steps):
+            one_step()
+            torch.cuda.synchronize()
+            for name, ms in m.last_kernel_ms():
+                acc.setdefault(name, []).append(ms)
+            acc.setdefault("update_bvh", []).append(m.last_update_bvh_ms())
+            acc.setdefault("raytrace_total", []).append(m.last_raytrace_ms())
+        m.enable_timing(False)
+        kern = {k: float(np.mean(v)) for k, v in acc.items() if v and v[0] >= 0}
+        cc = m.get_counters()
+        rays, cand, comp = cc[0:3], cc[3:6], cc[6:9]
+        pixels_rank = rays[0]
+        cands = {}
+        for s in range(3):
+            kind = "forward_nograd" if a.forward_only else "forward"
+            cands[f"forward_step{s}"] = algorithmic_bytes(kind, s, rays[s], cand[s], comp[s], pixels_rank)
+            if not a.forward_only:
+                cands[f"backward_step{s}"] = algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank)
+        dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
+        achieved = cands[dom] / (kern[dom] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                "traffic": None, "avg_kernel_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": cands[dom],
+                "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
+                "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
+                "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
+
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle import oracle as orc
+
+        cw, ch = (int(x) for x in a.cpu_sample.split("x"))
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        o = orc.Oracle(cw, ch, threads=cores)
+        o.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+        o.set_config(num_bounces=a.bounces, **syn.TRAIN_LOSS_WEIGHTS)
+        o.set_gaussians(g)
+        o.update_bvh()
+        ctg = syn.make_targets(cw, ch)
+        o.raytrace(not a.forward_only, targets=ctg)  # warm-up
+        t1 = time.perf_counter()
+        reps = 2
+        nr = 0
+        for _ in range(reps):
+            o.update_bvh()
+            out = o.raytrace(not a.forward_only, targets=ctg)
+            nr += int(out["effective_steps"].sum())
+        t_cpu = time.perf_counter() - t1
+        cpu = {"value": round(nr / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"CPU restatement of the reference algorithm (oracle/), same scene+camera+config at {cw}x{ch}, "
+                         f"{'forward' if a.forward_only else 'update_bvh + forward+backward'}, {reps} reps, OpenMP over rows"}
+
+    if rank == 0:
+        line = {
+            "metric": "Mrays/s fwd+bwd @1080p, 1M Gaussians" if not a.forward_only else "Mrays/s fwd-only @1080p",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic dense-init room+spheres cloud ({a.variant} opacity), N={N}, {W}x{H}, "
+                                   f"{'forward only' if a.forward_only else 'one training iteration: export + update_bvh + forward + backward + grad import'}, "
+                                   f"num_bounces={a.bounces}, jitter on, reference default config",
+                       "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce"},
+            "roofline": roof, "cpu_baseline": cpu, "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "status": int(status), "psnr_vs_optix": None,
+            "note": "vs_baseline null: the reference publishes no throughput number; PSNR vs OptiX is unmeasurable here (no NVIDIA "
+                    "hardware), parity is against the CPU oracle (tests/).",
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,8 @@ TORCH_LIB = os.path.join(OUT, "libraytracer.so")
 
 HIPCC = os.environ.get("HIPCC", shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+if os.environ.get("EGR_TRAVERSAL_STATS"):
+    HIP_FLAGS.append("-DEGR_TRAVERSAL_STATS=1")
 HIP_SOURCES = ["trace.hip", "epilogue.hip", "bvh.hip", "api.hip"]
 EXTRA_FLAGS = {"epilogue.hip": ["-ffp-contract=off"]}  # see the note at the top of csrc/epilogue.hip
 HEADERS = [os.path.join(CSRC, "egr_internal.hpp"), os.path.join(CSRC, "egr_device.hpp"), os.path.join(CSRC, "egr_state.hpp"), os.path.join(ROOT, "include", "egr_raytracer.h")]

@@ -1,6 +1,7 @@
 // extern "C" surface of libegr_hip.so (see include/egr_raytracer.h). Host-only code; the kernels live in
 // bvh.hip and trace.hip. The product fails loudly: every HIP error becomes a non-zero return + message.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "egr_internal.hpp"
@@ -61,6 +62,9 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     egr_context *c = new egr_context();
     c->device = device, c->width = width, c->height = height;
     c->fwd_capacity = ppll_forward_size > 0 ? ppll_forward_size : 1, c->bwd_capacity = ppll_backward_size > 0 ? ppll_backward_size : 1;
+    if (const char *e = getenv("EGR_PACKET_MODE")) c->packet_mode = atoi(e);           // tuning knobs
+    if (const char *e = getenv("EGR_PACKET_COS_MIN")) c->packet_cos_min = (float)atof(e);
+    if (const char *e = getenv("EGR_PACKET_ORIGIN_MAX")) c->packet_origin_max = (float)atof(e);
     int rc = guarded(c, [&] {
         egr_trace_alloc(c);
         EGR_HIP(hipEventCreate(&c->ev_rt0)), EGR_HIP(hipEventCreate(&c->ev_rt1));
@@ -156,11 +160,26 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
         EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
         const uint32_t *w = c->control_host;
         auto u64 = [&](int i) { return (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32); };
-        out->rays = u64(CW_RAYS), out->rays_step0 = u64(CW_RAYS0), out->candidates = u64(CW_CAND);
-        out->composited = u64(CW_COMP), out->composited_step0 = u64(CW_COMP0);
+        for (int s = 0; s < EGR_NSTEPS; s++)
+            out->rays[s] = u64(CW_RAYS + 2 * s), out->candidates[s] = u64(CW_CAND + 2 * s), out->composited[s] = u64(CW_COMP + 2 * s);
+        out->lifetime_rays = u64(CW_LIFE_RAYS);
+        out->lifetime_launches = w[CW_LIFE_LAUNCHES];
         out->status = w[CW_STATUS];
         out->bvh_depth = c->max_depth;
+        if (getenv("EGR_PRINT_TRAVERSAL_STATS")) {
+            for (int k = 0; k < 2; k++)
+                fprintf(stderr, "[egr stats %s] lane node visits %llu, lane leaf-box hits %llu, wave inner iterations %llu, wave outer rounds %llu\n", k ? "bounce" : "primary",
+                        (unsigned long long)u64(CW_DBG + 8 * k), (unsigned long long)u64(CW_DBG + 8 * k + 2), (unsigned long long)u64(CW_DBG + 8 * k + 4), (unsigned long long)u64(CW_DBG + 8 * k + 6));
+            for (int k = 0; k < 2; k++)
+                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime, 100MHz ticks) traversal %llu composite %llu\n", k ? "bounce" : "primary",
+                        (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2));
+        }
     });
+}
+
+int egr_reset_lifetime_counters(egr_context *c, void *stream) {
+    if (!c) return 1;
+    return guarded(c, [&] { EGR_HIP(hipMemsetAsync(c->control + CW_LIFE_RAYS, 0, 4 * sizeof(uint32_t), (hipStream_t)stream)); });
 }
 
 int egr_enable_timing(egr_context *c, int enable) {

@@ -60,18 +60,24 @@ struct DeviceView { // everything a kernel needs, passed by value
     float *state;          // internal per-ray state, SoA by task-linear index (see trace.hip)
     uint32_t state_stride; // = padded number of task-linear rays
     uint32_t *control;     // device counters (see ControlWord)
+    int packet_mode;       // 0 per-lane walk only, 1 packet walk for primary rays, 2 adaptive (coherence test per tile)
+    float packet_cos_min, packet_origin_max;
 };
 
 enum ControlWord : int {
-    CW_QUEUE0 = 0,      // task queue heads, one per step kernel (forward 0..2, backward 3..5, finish 6)
+    CW_QUEUE0 = 0,      // task queue heads, one per step kernel (forward 0..2, backward 3..5)
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
-    CW_RAYS = 10,       // 64-bit counters take two words each
-    CW_RAYS0 = 12,
-    CW_CAND = 14,
-    CW_COMP = 16,
-    CW_COMP0 = 18,
-    CW_COUNT = 32
+    CW_RAYS = 10,       // per-step 64-bit counters (two words each): rays[3], candidates[3], composited[3]
+    CW_CAND = 16,
+    CW_COMP = 22,
+    CW_RESET_END = 28,  // words [0, CW_RESET_END) are zeroed by every launch
+    CW_LIFE_RAYS = 28,  // lifetime totals (since egr_create / egr_reset_lifetime_counters), 64-bit
+    CW_LIFE_LAUNCHES = 30,
+    CW_DBG = 32,        // optional traversal statistics (EGR_TRAVERSAL_STATS builds): 8 x 64-bit
+    CW_DBG2 = 48,       // per-phase s_memtime sums: [primary traversal, primary composite, bounce traversal, bounce composite]
+    CW_XQ = 64,         // XCD-affine task queues: [kernel 0..5][xcd 0..7] heads
+    CW_COUNT = 128
 };
 
 struct KernelStamp {
@@ -127,6 +133,8 @@ struct egr_context {
     bool have_rt = false, have_ub = false;
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
+    int packet_mode = 1;
+    float packet_cos_min = 0.98f, packet_origin_max = 0.25f;
     std::string last_error;
 };
 

@@ -377,9 +377,12 @@ struct Raytracer : torch::CustomClassHolder {
     std::vector<int64_t> get_counters() { // synchronises
         egr_counters c{};
         check(egr_get_counters(ctx, &c, current_stream()), "get_counters");
-        return {(int64_t)c.rays, (int64_t)c.rays_step0, (int64_t)c.candidates, (int64_t)c.composited, (int64_t)c.composited_step0,
-                (int64_t)c.status, (int64_t)c.bvh_depth};
+        // [rays0..2, candidates0..2, composited0..2, lifetime_rays, lifetime_launches, status, bvh_depth]
+        return {(int64_t)c.rays[0], (int64_t)c.rays[1], (int64_t)c.rays[2], (int64_t)c.candidates[0], (int64_t)c.candidates[1],
+                (int64_t)c.candidates[2], (int64_t)c.composited[0], (int64_t)c.composited[1], (int64_t)c.composited[2],
+                (int64_t)c.lifetime_rays, (int64_t)c.lifetime_launches, (int64_t)c.status, (int64_t)c.bvh_depth};
     }
+    void reset_lifetime_counters() { check(egr_reset_lifetime_counters(ctx, current_stream()), "reset_lifetime_counters"); }
     void enable_timing(bool on) { egr_enable_timing(ctx, on ? 1 : 0); }
     double last_raytrace_ms() { return egr_last_raytrace_ms(ctx); }
     double last_update_bvh_ms() { return egr_last_update_bvh_ms(ctx); }
@@ -453,6 +456,7 @@ struct Raytracer : torch::CustomClassHolder {
             // additions for multi-GPU tile partitioning, measurement and tests
             .def("set_partition", &Raytracer::set_partition)
             .def("get_counters", &Raytracer::get_counters)
+            .def("reset_lifetime_counters", &Raytracer::reset_lifetime_counters)
             .def("enable_timing", &Raytracer::enable_timing)
             .def("last_raytrace_ms", &Raytracer::last_raytrace_ms)
             .def("last_update_bvh_ms", &Raytracer::last_update_bvh_ms)

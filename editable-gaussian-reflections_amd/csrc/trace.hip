@@ -24,10 +24,26 @@
 
 namespace {
 
-EGR_DI uint32_t wave_next_task(uint32_t *queue) {
-    uint32_t t = 0;
-    if (threadIdx.x == 0) t = atomicAdd(queue, 1u);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+// XCD-affine persistent scheduling: the task range is cut into 8 contiguous chunks (contiguous image bands), one
+// queue head per chunk. A wave first drains the chunk of "its" XCD (workgroup b is observed to run on XCD b % 8;
+// used for speed only, any placement is correct), then steals from the others. Each XCD's private 4 MiB L2 then
+// holds one band's BVH nodes / Gaussian records instead of the whole frame's, and the single shared head no
+// longer serialises 6144 pullers (microarch guide, "dequeue": shard the head per XCD above 64 pullers).
+EGR_DI uint32_t wave_next_task(uint32_t *heads, uint32_t num_tasks, uint32_t &cur_q) {
+    const uint32_t chunk = ((num_tasks + 7u) / 8u + 3u) & ~3u;
+    for (uint32_t tries = 0; tries < 8u; tries++) {
+        const uint32_t q = (cur_q + tries) & 7u;
+        const uint32_t beg = q * chunk, end = min(beg + chunk, num_tasks);
+        if (beg >= end) continue;
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(heads + q, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (beg + t < end) {
+            cur_q = q;
+            return beg + t;
+        }
+    }
+    return 0xFFFFFFFFu;
 }
 EGR_DI uint32_t wave_sum_u32(uint32_t x) {
 #pragma unroll
@@ -81,6 +97,28 @@ EGR_DI void closest_point(f3 lo, f3 ld, f3 &dhat, float &t, f3 &u) { // shaders.
     t = tl / norm;
     u = lo + tl * dhat;
 }
+// Wave-uniform node fetch: constant address space + uniform index => one s_load_dwordx8 through the scalar cache
+// (the tree is read-only for the whole launch) instead of a 64-lane vector load.
+typedef float egr_v8f __attribute__((ext_vector_type(8)));
+EGR_DI void load_node_uniform(const float4 *nodes, uint32_t un, float4 &n0, float4 &n1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) egr_v8f *p = (const __attribute__((address_space(4))) egr_v8f *)nodes;
+    const egr_v8f x = p[un];
+    n0 = make_float4(x[0], x[1], x[2], x[3]);
+    n1 = make_float4(x[4], x[5], x[6], x[7]);
+#else
+    n0 = nodes[2 * un], n1 = nodes[2 * un + 1];
+#endif
+}
+typedef float egr_v4f __attribute__((ext_vector_type(4)));
+EGR_DI float4 load_f4_uniform(const float4 *base, uint32_t idx) { // idx must be wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+    const egr_v4f x = ((const __attribute__((address_space(4))) egr_v4f *)base)[idx];
+    return make_float4(x[0], x[1], x[2], x[3]);
+#else
+    return base[idx];
+#endif
+}
 // OptiX's instance test restated: segment [tmin,tmax] of the object-space ray vs the unit cube.
 EGR_DI bool hits_unit_cube(f3 lo, f3 ld, float tmin, float tmax) {
     f3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
@@ -103,7 +141,10 @@ EGR_DI bool hits_unit_cube(f3 lo, f3 ld, float tmin, float tmax) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_prologue(DeviceView v, int grads) {
     int t = threadIdx.x;
-    if (t < CW_COUNT) v.control[t] = 0;
+    if (t < CW_RESET_END) v.control[t] = 0;
+    if (t >= CW_DBG && t < CW_COUNT) v.control[t] = 0;
+    if (t < 16) v.control[CW_DBG2 + t] = 0;
+    if (t < 48) v.control[CW_XQ + t] = 0;
     if (t == 0) {
         *v.meta.grads_enabled = grads ? 1 : 0;   // metadata.h:29
         *v.meta.total_num_calls += 1;             // metadata.h:30
@@ -111,7 +152,13 @@ __global__ void k_prologue(DeviceView v, int grads) {
 }
 __global__ void k_epilogue(DeviceView v, int grads) {
     // raytracer.cpp:91-93 (the reference adds 1 whenever accumulate_samples is set)
-    if (threadIdx.x == 0 && *v.cfg.accumulate_samples) *v.fb.accumulated_sample_count += 1;
+    if (threadIdx.x == 0) {
+        if (*v.cfg.accumulate_samples) *v.fb.accumulated_sample_count += 1;
+        unsigned long long rays = 0;
+        for (int s = 0; s < EGR_NSTEPS; s++) rays += *reinterpret_cast<unsigned long long *>(v.control + CW_RAYS + 2 * s);
+        *reinterpret_cast<unsigned long long *>(v.control + CW_LIFE_RAYS) += rays;
+        v.control[CW_LIFE_LAUNCHES] += 1;
+    }
 }
 // per-launch live record: activated appearance + (opacity, sigma). Reads the CURRENT parameter tensors, like
 // the reference's read_* helpers do inside the launch (utils/helpers.cu:10-33), while inst_w/inst_m stay snapshots.
@@ -148,9 +195,10 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     if (step > num_bounces) return;
 
     uint32_t w_rays = 0, w_cand = 0, w_comp = 0;
+    uint32_t cur_q = blockIdx.x & 7u;
 
     for (;;) {
-        const uint32_t task = wave_next_task(v.control + CW_QUEUE0 + step);
+        const uint32_t task = wave_next_task(v.control + CW_XQ + 8 * step, v.num_tasks, cur_q);
         if (task >= v.num_tasks) break;
         const TaskGeom tg = task_geom(v, task, lane);
         StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
@@ -176,64 +224,169 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         }
         if (__ballot(active) == 0ull) continue;
 
+#ifdef EGR_TRAVERSAL_STATS
+        const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- R2: traversal + candidate evaluation (shaders.cu:9-75) -------------------------------------
+        // Two DECOUPLED per-lane loops instead of one "find a leaf, wait for the wave, evaluate" loop: with a
+        // per-round rendezvous the wave pays max-over-lanes of every leaf search (measured 18 % / 11 % SIMT
+        // efficiency on primary / bounce rays). Phase A only walks the threaded tree and queues the leaf ids whose
+        // box the segment overlaps; phase B evaluates the queue. The queue lives in the lane's key column
+        // (ids are overwritten by keys, write index <= read index).
         const bool ray_ok = active && finite3(ro) && finite3(rd); // NaN rays (ggx_brdf.h:163) hit nothing
         const f3 inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        uint32_t node = ray_ok ? 0u : END;
+        uint32_t nleaf = 0;   // write cursor of the leaf queue (ids), >= cnt
         uint32_t cnt = 0, traversed = 0;
         float full_T = 1.0f;
         bool overflow = false;
-        for (;;) {
-            uint32_t prim = EGR_INTERNAL_NODE;
-            while (node < END) { // advance to the next leaf whose box the segment overlaps
-                float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
-                bool hit = slab_hit(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), ro, inv, near_plane, far_plane);
-                uint32_t skip = f2u(n0.w), p = f2u(n1.w);
-                if (!hit) {
-                    node = skip;
-                } else if (p == EGR_INTERNAL_NODE) {
-                    node = node + 1;
-                } else {
-                    prim = p;
-                    node = skip;
-                    break;
-                }
+#ifdef EGR_TRAVERSAL_STATS
+        uint32_t st_visits = 0, st_leafhits = 0, st_inner = 0, st_outer = 0;
+#endif
+        // Tile coherence decides HOW phase A walks the tree. Coherent tiles (all primary tiles, mirror-like bounces)
+        // walk it as ONE packet: the node index is wave-uniform, the node is fetched with scalar loads (one request
+        // per wave instead of 64 divergent 16-B gathers, which is what bounds the per-lane walk: ~1 lane-load/clk/CU),
+        // every lane tests its own ray and a node is entered when ANY lane overlaps it. Incoherent tiles walk per lane.
+        bool packet;
+        {
+            f3 dsum = mk3(ray_ok ? rd.x : 0.0f, ray_ok ? rd.y : 0.0f, ray_ok ? rd.z : 0.0f);
+            f3 osum = mk3(ray_ok ? ro.x : 0.0f, ray_ok ? ro.y : 0.0f, ray_ok ? ro.z : 0.0f);
+            float nok = ray_ok ? 1.0f : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                dsum.x += __shfl_xor(dsum.x, off), dsum.y += __shfl_xor(dsum.y, off), dsum.z += __shfl_xor(dsum.z, off);
+                osum.x += __shfl_xor(osum.x, off), osum.y += __shfl_xor(osum.y, off), osum.z += __shfl_xor(osum.z, off);
+                nok += __shfl_xor(nok, off);
             }
-            if (__ballot(prim != EGR_INTERNAL_NODE) == 0ull) break;
-            if (prim != EGR_INTERNAL_NODE) {
-                f3 lo, ld;
-                object_ray(v.inst_w, prim, ro, rd, lo, ld);
-                if (hits_unit_cube(lo, ld, near_plane, far_plane)) {
-                    traversed++;                                        // shaders.cu:33
-                    if (!(dot(lo, ld) > 0.0f)) {                        // :36
-                        f3 dhat, u;
-                        float t;
-                        closest_point(lo, ld, dhat, t, u);              // :41-45
-                        float sq = dot(u, u);
-                        bool accept = !(sq > 1.0f);                     // :48-51
-                        if (accept && step != 0 && t < backfacing_max_dist) { // :54-61 (world normal . object dir)
-                            f3 gn = mk3(v.g.normal[3 * prim], v.g.normal[3 * prim + 1], v.g.normal[3 * prim + 2]);
-                            if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) accept = false;
-                        }
-                        if (accept) {
-                            float4 a2 = app[3 * prim + 2]; // (f0.z, roughness, opacity, sigma)
-                            f3 x = u * a2.w;                                     // :64
-                            float gaussval = eval_gaussian_sq(dot(x, x), exp_power); // :65
-                            float alpha = EGR_MAX_ALPHA * gaussval * a2.z;       // kernel.cu:14-16
-                            full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
-                            if (cnt < v.cand_cap) {
-                                keys[(size_t)cnt * EGR_WAVE + lane] = t;
-                                vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(prim));
-                                cnt++;
-                            } else {
-                                overflow = true;
+            f3 dmean = normalize(dsum), omean = osum * (1.0f / fmaxf(nok, 1.0f));
+            float cmin = ray_ok ? dot(rd, dmean) : 1.0f, omax = ray_ok ? length(ro - omean) : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, off)), omax = fmaxf(omax, __shfl_xor(omax, off));
+            packet = v.packet_mode == 2 ? (cmin >= v.packet_cos_min && omax <= v.packet_origin_max) : (v.packet_mode == 1 && step == 0);
+            packet = __builtin_amdgcn_readfirstlane(packet ? 1 : 0) != 0;
+        }
+        uint32_t node = ray_ok ? 0u : END;
+        uint32_t unode = 0u; // wave-uniform cursor of the packet walk
+        for (;;) {
+            // ---- phase A: queue the ids of the leaves whose box this lane's segment overlaps ----
+            if (packet) {
+                // fused walk + evaluation: the leaf's transform and live record are wave-uniform too, so they come
+                // through the scalar cache as well and every lane whose segment overlaps the leaf box evaluates its
+                // own ray against them. No per-lane gathers at all on this path.
+                while (unode < END) {
+                    const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)unode);
+                    float4 n0, n1;
+                    load_node_uniform(nodes, un, n0, n1); // (tried: 8-node window via one coalesced vector load + v_readlane; slower)
+                    const bool hit = ray_ok && slab_hit(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), ro, inv, near_plane, far_plane);
+                    const uint32_t skip = f2u(n0.w), p = f2u(n1.w);
+                    const bool any = __ballot(hit) != 0ull;
+#ifdef EGR_TRAVERSAL_STATS
+                    st_visits += hit ? 1u : 0u;
+                    st_inner += (lane == 0);
+                    st_leafhits += (hit && p != EGR_INTERNAL_NODE) ? 1u : 0u;
+                    st_outer += (lane == 0 && any && p != EGR_INTERNAL_NODE);
+#endif
+                    if (any && p != EGR_INTERNAL_NODE) {
+                        const float4 w0 = load_f4_uniform(v.inst_w, 3 * p), w1 = load_f4_uniform(v.inst_w, 3 * p + 1), w2 = load_f4_uniform(v.inst_w, 3 * p + 2);
+                        const float4 a2 = load_f4_uniform(app, 3 * p + 2);
+                        if (hit) {
+                            const f3 lo = mk3(w0.x * ro.x + w0.y * ro.y + w0.z * ro.z + w0.w, w1.x * ro.x + w1.y * ro.y + w1.z * ro.z + w1.w,
+                                              w2.x * ro.x + w2.y * ro.y + w2.z * ro.z + w2.w);
+                            const f3 ld = mk3(w0.x * rd.x + w0.y * rd.y + w0.z * rd.z, w1.x * rd.x + w1.y * rd.y + w1.z * rd.z,
+                                              w2.x * rd.x + w2.y * rd.y + w2.z * rd.z);
+                            if (hits_unit_cube(lo, ld, near_plane, far_plane)) {
+                                traversed++;                                    // shaders.cu:33
+                                if (!(dot(lo, ld) > 0.0f)) {                    // :36
+                                    f3 dhat, u;
+                                    float t;
+                                    closest_point(lo, ld, dhat, t, u);          // :41-45
+                                    bool accept = !(dot(u, u) > 1.0f);          // :48-51
+                                    if (accept && step != 0 && t < backfacing_max_dist) { // :54-61
+                                        f3 gn = mk3(v.g.normal[3 * p], v.g.normal[3 * p + 1], v.g.normal[3 * p + 2]);
+                                        if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) accept = false;
+                                    }
+                                    if (accept) {
+                                        f3 x = u * a2.w;                                          // :64
+                                        float gaussval = eval_gaussian_sq(dot(x, x), exp_power);   // :65
+                                        float alpha = EGR_MAX_ALPHA * gaussval * a2.z;             // kernel.cu:14-16
+                                        full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
+                                        if (cnt < v.cand_cap) {
+                                            keys[(size_t)cnt * EGR_WAVE + lane] = t;
+                                            vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(p));
+                                            cnt++;
+                                        } else {
+                                            overflow = true;
+                                        }
+                                    }
+                                }
                             }
                         }
                     }
+                    unode = (any && p == EGR_INTERNAL_NODE) ? un + 1 : skip;
+                }
+                node = END;
+                nleaf = cnt;
+            } else {
+                while (node < END && nleaf < v.cand_cap) {
+                    float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
+                    bool hit = slab_hit(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), ro, inv, near_plane, far_plane);
+                    uint32_t skip = f2u(n0.w), p = f2u(n1.w);
+#ifdef EGR_TRAVERSAL_STATS
+                    st_visits++;
+                    if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
+#endif
+                    if (hit && p != EGR_INTERNAL_NODE) keys[(size_t)nleaf * EGR_WAVE + lane] = u2f(p), nleaf++;
+                    node = (hit && p == EGR_INTERNAL_NODE) ? node + 1 : skip;
                 }
             }
+#ifdef EGR_TRAVERSAL_STATS
+            st_leafhits += nleaf - cnt;
+#endif
+            // ---- phase B: evaluate the queued leaves [cnt, nleaf), compacting accepted hits to [.., cnt) ----
+            const uint32_t qbeg = cnt;
+            for (uint32_t q = qbeg; q < nleaf; q++) {
+                const uint32_t prim = f2u(keys[(size_t)q * EGR_WAVE + lane]);
+#ifdef EGR_TRAVERSAL_STATS
+                st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
+#endif
+                f3 lo, ld;
+                object_ray(v.inst_w, prim, ro, rd, lo, ld);
+                if (!hits_unit_cube(lo, ld, near_plane, far_plane)) continue;
+                traversed++;                                        // shaders.cu:33
+                if (dot(lo, ld) > 0.0f) continue;                   // :36
+                f3 dhat, u;
+                float t;
+                closest_point(lo, ld, dhat, t, u);                  // :41-45
+                if (dot(u, u) > 1.0f) continue;                     // :48-51
+                if (step != 0 && t < backfacing_max_dist) {         // :54-61 (world normal . object dir)
+                    f3 gn = mk3(v.g.normal[3 * prim], v.g.normal[3 * prim + 1], v.g.normal[3 * prim + 2]);
+                    if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) continue;
+                }
+                float4 a2 = app[3 * prim + 2]; // (f0.z, roughness, opacity, sigma)
+                f3 x = u * a2.w;                                     // :64
+                float gaussval = eval_gaussian_sq(dot(x, x), exp_power); // :65
+                float alpha = EGR_MAX_ALPHA * gaussval * a2.z;       // kernel.cu:14-16
+                full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
+                keys[(size_t)cnt * EGR_WAVE + lane] = t;             // cnt <= q: never overtakes the read cursor
+                vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(prim));
+                cnt++;
+            }
+            nleaf = cnt; // the queue restarts right behind the accepted hits
+            const bool more = packet ? (unode < END) : (node < END);
+            if (more && cnt >= v.cand_cap) { // accepted hits alone fill the capacity: drop the rest, raise the flag
+                overflow = true;
+                node = END;
+                if (packet) unode = END;
+            }
+            if (__ballot(packet ? (unode < END) : (node < END)) == 0ull) break;
         }
 
+#ifdef EGR_TRAVERSAL_STATS
+        const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+        {
+            uint32_t a = wave_sum_u32(st_visits), b = wave_sum_u32(st_leafhits), c2 = wave_sum_u32(st_inner), d = wave_sum_u32(st_outer);
+            if (lane == 0) add64(v.control, CW_DBG + 8 * (step > 0), a), add64(v.control, CW_DBG + 8 * (step > 0) + 2, b), add64(v.control, CW_DBG + 8 * (step > 0) + 4, c2), add64(v.control, CW_DBG + 8 * (step > 0) + 6, d);
+        }
+#endif
         // ---- R3: depth-ordered compositing (forward_pass.cu:48-137) --------------------------------------
         f3 c_rgb = mk3(0, 0, 0), c_n = mk3(0, 0, 0), c_f0 = mk3(0, 0, 0);
         float c_rough = 0.0f, c_depth = 0.0f, T = 1.0f;
@@ -249,7 +402,20 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 float best = 3.4028235e38f;
                 uint32_t bi = 0xFFFFFFFFu;
                 if (running) {
-                    for (uint32_t k = 0; k < cnt; k++) {
+                    // the scan is a chain of independent, coalesced 256-B row loads: issue 8 before consuming any,
+                    // otherwise every iteration pays a full L2 round trip (measured: the scan was latency-bound)
+                    uint32_t k = 0;
+                    for (; k + 8 <= cnt; k += 8) {
+                        float tk[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) tk[j] = keys[(size_t)(k + j) * EGR_WAVE + lane];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            bool after = (tk[j] > t_prev) || (tk[j] == t_prev && (k + j) > k_prev && k_prev != 0xFFFFFFFFu);
+                            if (after && tk[j] < best) best = tk[j], bi = k + j;
+                        }
+                    }
+                    for (; k < cnt; k++) {
                         float tk = keys[(size_t)k * EGR_WAVE + lane];
                         bool after = (tk > t_prev) || (tk == t_prev && k > k_prev && k_prev != 0xFFFFFFFFu);
                         if (after && tk < best) best = tk, bi = k;
@@ -299,6 +465,15 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         }
         if (overflow && active) atomicOr(v.control + CW_STATUS, EGR_STATUS_CANDIDATE_OVERFLOW);
 
+#ifdef EGR_TRAVERSAL_STATS
+        {
+            const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 4 * (step > 0)), tm1 - tm0);
+                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 4 * (step > 0) + 2), tm2 - tm1);
+            }
+        }
+#endif
         // ---- raw step results; R4/R5 (tail renormalisation, bounce sampling) run in k_step_epilogue (epilogue.hip),
         // which is compiled without fma contraction (see the note there).
         if (active) {
@@ -317,25 +492,59 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         w_comp += active ? nhits : 0u;
     }
     w_rays = wave_sum_u32(w_rays), w_cand = wave_sum_u32(w_cand), w_comp = wave_sum_u32(w_comp);
-    if (lane == 0) {
-        add64(v.control, CW_RAYS, w_rays), add64(v.control, CW_CAND, w_cand), add64(v.control, CW_COMP, w_comp);
-        if (step == 0) add64(v.control, CW_RAYS0, w_rays), add64(v.control, CW_COMP0, w_comp);
-    }
+    if (lane == 0) add64(v.control, CW_RAYS + 2 * step, w_rays), add64(v.control, CW_CAND + 2 * step, w_cand), add64(v.control, CW_COMP + 2 * step, w_comp);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward: one step, walked newest (farthest) hit first  (backward_pass.cu:3-222)
 // ---------------------------------------------------------------------------------------------------------
+// Gradient pre-reduction (cdna guide, Guideline 12): the 64 rays of a tile composite the same few dozen Gaussians,
+// so per-hit contributions are first summed in a per-wave LDS hash table (ds_add_f32, open addressing on the
+// gaussian id) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
+#define EGR_GT_SLOTS 128
+#define EGR_GT_COMPS 22
+#define EGR_GT_EMPTY 0xFFFFFFFFu
+enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_NORMAL = 14, GC_F0 = 17, GC_ROUGH = 20, GC_WEIGHT = 21 };
+
+EGR_DI void grad_table_flush(const egr_gaussians &g, uint32_t *gt_keys, float *gt_vals, int lane) {
+    __syncthreads();
+    for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) {
+        const uint32_t gid = gt_keys[s];
+        if (gid == EGR_GT_EMPTY) continue;
+        gt_keys[s] = EGR_GT_EMPTY;
+        float x[EGR_GT_COMPS];
+#pragma unroll
+        for (int c = 0; c < EGR_GT_COMPS; c++) x[c] = gt_vals[c * EGR_GT_SLOTS + s], gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
+#define EGR_FL(ptr, idx, c) if (x[c] != 0.0f) atomicAdd(&(ptr)[idx], x[c]);
+        EGR_FL(g.dL_dopacity, gid, GC_OPA)
+        EGR_FL(g.dL_dscale, 3 * gid, GC_SCALE) EGR_FL(g.dL_dscale, 3 * gid + 1, GC_SCALE + 1) EGR_FL(g.dL_dscale, 3 * gid + 2, GC_SCALE + 2)
+        EGR_FL(g.dL_dmean, 3 * gid, GC_MEAN) EGR_FL(g.dL_dmean, 3 * gid + 1, GC_MEAN + 1) EGR_FL(g.dL_dmean, 3 * gid + 2, GC_MEAN + 2)
+        EGR_FL(g.dL_drotation, 4 * gid, GC_ROT) EGR_FL(g.dL_drotation, 4 * gid + 1, GC_ROT + 1) EGR_FL(g.dL_drotation, 4 * gid + 2, GC_ROT + 2) EGR_FL(g.dL_drotation, 4 * gid + 3, GC_ROT + 3)
+        EGR_FL(g.dL_drgb, 3 * gid, GC_RGB) EGR_FL(g.dL_drgb, 3 * gid + 1, GC_RGB + 1) EGR_FL(g.dL_drgb, 3 * gid + 2, GC_RGB + 2)
+        EGR_FL(g.dL_dnormal, 3 * gid, GC_NORMAL) EGR_FL(g.dL_dnormal, 3 * gid + 1, GC_NORMAL + 1) EGR_FL(g.dL_dnormal, 3 * gid + 2, GC_NORMAL + 2)
+        EGR_FL(g.dL_df0, 3 * gid, GC_F0) EGR_FL(g.dL_df0, 3 * gid + 1, GC_F0 + 1) EGR_FL(g.dL_df0, 3 * gid + 2, GC_F0 + 2)
+        EGR_FL(g.dL_droughness, gid, GC_ROUGH) EGR_FL(g.total_weight, gid, GC_WEIGHT)
+#undef EGR_FL
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
     const int lane = threadIdx.x;
+    __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
+    __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
+    for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
+    for (int s = lane; s < EGR_GT_COMPS * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
+    __syncthreads();
     const float exp_power = *v.cfg.exp_power;
     const float eps_scale_grad = *v.cfg.eps_scale_grad;
     const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
     if (step > num_bounces) return;
     const egr_gaussians &g = v.g;
+    uint32_t cur_q = blockIdx.x & 7u;
 
     for (;;) {
-        const uint32_t task = wave_next_task(v.control + CW_QUEUE0 + 3 + step);
+        const uint32_t task = wave_next_task(v.control + CW_XQ + 8 * (3 + step), v.num_tasks, cur_q);
         if (task >= v.num_tasks) break;
         uint32_t blk = v.task_last_block[(size_t)step * v.num_tasks + task];
         if (blk == 0xFFFFFFFFu) continue;
@@ -390,6 +599,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
         f3 prev_rgb = mk3(0, 0, 0), w_rgb = mk3(0, 0, 0), prev_n = mk3(0, 0, 0), w_n = mk3(0, 0, 0), prev_f0 = mk3(0, 0, 0), w_f0 = mk3(0, 0, 0);
         float prev_rough = 0, w_rough = 0, prev_depth = 0, w_depth = 0;
         const uint32_t nblocks = (max_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
+        uint32_t new_slots = 0;
         for (uint32_t b = nblocks; b-- > 0;) {
             const float4 *rows = v.hit_arena + (size_t)blk * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE;
             for (int row = EGR_HIT_BLOCK_ROWS - 1; row >= 0; row--) {
@@ -471,25 +681,50 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     const float dd = dL_dr * qu.x + dL_dx * qu.y + dL_dy * qu.z + dL_dz * qu.w; // activations.cu:71-73
                     const float inv3 = 1.0f / (qn * qn * qn), inv1 = 1.0f / qn;
 
-                    // :210-220 flush (hardware fp32 atomics; order across rays is nondeterministic, as upstream)
-                    atomicAdd(&g.dL_dopacity[gid], d_opacity);
-                    atomicAdd(&g.dL_dscale[3 * gid], d_scale.x), atomicAdd(&g.dL_dscale[3 * gid + 1], d_scale.y), atomicAdd(&g.dL_dscale[3 * gid + 2], d_scale.z);
-                    atomicAdd(&g.dL_dmean[3 * gid], d_mean.x), atomicAdd(&g.dL_dmean[3 * gid + 1], d_mean.y), atomicAdd(&g.dL_dmean[3 * gid + 2], d_mean.z);
-                    atomicAdd(&g.dL_drotation[4 * gid], dd * -qu.x * inv3 + dL_dr * inv1);
-                    atomicAdd(&g.dL_drotation[4 * gid + 1], dd * -qu.y * inv3 + dL_dx * inv1);
-                    atomicAdd(&g.dL_drotation[4 * gid + 2], dd * -qu.z * inv3 + dL_dy * inv1);
-                    atomicAdd(&g.dL_drotation[4 * gid + 3], dd * -qu.w * inv3 + dL_dz * inv1);
-                    atomicAdd(&g.dL_drgb[3 * gid], d_rgb.x), atomicAdd(&g.dL_drgb[3 * gid + 1], d_rgb.y), atomicAdd(&g.dL_drgb[3 * gid + 2], d_rgb.z);
-                    if (step == 0) {
-                        atomicAdd(&g.dL_dnormal[3 * gid], d_n.x), atomicAdd(&g.dL_dnormal[3 * gid + 1], d_n.y), atomicAdd(&g.dL_dnormal[3 * gid + 2], d_n.z);
-                        atomicAdd(&g.dL_df0[3 * gid], d_f0.x), atomicAdd(&g.dL_df0[3 * gid + 1], d_f0.y), atomicAdd(&g.dL_df0[3 * gid + 2], d_f0.z);
-                        atomicAdd(&g.dL_droughness[gid], d_rough);
+                    // :210-220 flush: into the LDS table when a slot is found within 8 probes, else straight to global
+                    const float d_rot0 = dd * -qu.x * inv3 + dL_dr * inv1, d_rot1 = dd * -qu.y * inv3 + dL_dx * inv1;
+                    const float d_rot2 = dd * -qu.z * inv3 + dL_dy * inv1, d_rot3 = dd * -qu.w * inv3 + dL_dz * inv1;
+                    uint32_t slot = (gid * 2654435761u) >> 25; // top 7 bits -> [0,128)
+                    bool found = false;
+#pragma unroll 1
+                    for (int probe = 0; probe < 8; probe++) {
+                        const uint32_t old = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, gid);
+                        if (old == EGR_GT_EMPTY || old == gid) { found = true; break; }
+                        slot = (slot + 1) & (EGR_GT_SLOTS - 1);
                     }
-                    atomicAdd(&g.total_weight[gid], weight);
+                    if (found) {
+                        new_slots += 1;
+#define EGR_TA(c, val) atomicAdd(&gt_vals[(c) * EGR_GT_SLOTS + slot], (val));
+                        EGR_TA(GC_OPA, d_opacity) EGR_TA(GC_SCALE, d_scale.x) EGR_TA(GC_SCALE + 1, d_scale.y) EGR_TA(GC_SCALE + 2, d_scale.z)
+                        EGR_TA(GC_MEAN, d_mean.x) EGR_TA(GC_MEAN + 1, d_mean.y) EGR_TA(GC_MEAN + 2, d_mean.z)
+                        EGR_TA(GC_ROT, d_rot0) EGR_TA(GC_ROT + 1, d_rot1) EGR_TA(GC_ROT + 2, d_rot2) EGR_TA(GC_ROT + 3, d_rot3)
+                        EGR_TA(GC_RGB, d_rgb.x) EGR_TA(GC_RGB + 1, d_rgb.y) EGR_TA(GC_RGB + 2, d_rgb.z)
+                        if (step == 0) {
+                            EGR_TA(GC_NORMAL, d_n.x) EGR_TA(GC_NORMAL + 1, d_n.y) EGR_TA(GC_NORMAL + 2, d_n.z)
+                            EGR_TA(GC_F0, d_f0.x) EGR_TA(GC_F0 + 1, d_f0.y) EGR_TA(GC_F0 + 2, d_f0.z) EGR_TA(GC_ROUGH, d_rough)
+                        }
+                        EGR_TA(GC_WEIGHT, weight)
+#undef EGR_TA
+                    } else {
+                        atomicAdd(&g.dL_dopacity[gid], d_opacity);
+                        atomicAdd(&g.dL_dscale[3 * gid], d_scale.x), atomicAdd(&g.dL_dscale[3 * gid + 1], d_scale.y), atomicAdd(&g.dL_dscale[3 * gid + 2], d_scale.z);
+                        atomicAdd(&g.dL_dmean[3 * gid], d_mean.x), atomicAdd(&g.dL_dmean[3 * gid + 1], d_mean.y), atomicAdd(&g.dL_dmean[3 * gid + 2], d_mean.z);
+                        atomicAdd(&g.dL_drotation[4 * gid], d_rot0), atomicAdd(&g.dL_drotation[4 * gid + 1], d_rot1);
+                        atomicAdd(&g.dL_drotation[4 * gid + 2], d_rot2), atomicAdd(&g.dL_drotation[4 * gid + 3], d_rot3);
+                        atomicAdd(&g.dL_drgb[3 * gid], d_rgb.x), atomicAdd(&g.dL_drgb[3 * gid + 1], d_rgb.y), atomicAdd(&g.dL_drgb[3 * gid + 2], d_rgb.z);
+                        if (step == 0) {
+                            atomicAdd(&g.dL_dnormal[3 * gid], d_n.x), atomicAdd(&g.dL_dnormal[3 * gid + 1], d_n.y), atomicAdd(&g.dL_dnormal[3 * gid + 2], d_n.z);
+                            atomicAdd(&g.dL_df0[3 * gid], d_f0.x), atomicAdd(&g.dL_df0[3 * gid + 1], d_f0.y), atomicAdd(&g.dL_df0[3 * gid + 2], d_f0.z);
+                            atomicAdd(&g.dL_droughness[gid], d_rough);
+                        }
+                        atomicAdd(&g.total_weight[gid], weight);
+                    }
                 }
             }
             blk = f2u(rows[0].x); // header: previous (older) block of this task
         }
+        (void)new_slots;
+        grad_table_flush(g, gt_keys, gt_vals, lane); // one flush per tile; probe overflow already went to global
     }
 }
 
@@ -609,6 +844,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
+    v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
     return v;
 }
 

@@ -96,13 +96,14 @@ typedef struct egr_stats {
 
 /* Whole-launch work counters (not in the reference; used for the roofline's algorithmic bytes). */
 typedef struct egr_counters {
-    uint64_t rays;            /* sum over pixels of executed steps                     */
-    uint64_t rays_step0;      /* primary rays                                          */
-    uint64_t candidates;      /* sum of cube-overlap candidates (Hc)                   */
-    uint64_t composited;      /* sum of composited hits over all steps (Kc)            */
-    uint64_t composited_step0;
-    uint32_t status;          /* EGR_STATUS_* bit mask of the last launch              */
+    uint64_t rays[EGR_NUM_STEPS];        /* rays traced per bounce step (a ray = one pixel x step)            */
+    uint64_t candidates[EGR_NUM_STEPS];  /* cube-overlap candidates per step (Hc = intersection invocations) */
+    uint64_t composited[EGR_NUM_STEPS];  /* composited hits per step (Kc)                                     */
+    uint64_t lifetime_rays;              /* rays of ALL launches since egr_create / egr_reset_lifetime_counters */
+    uint32_t lifetime_launches;
+    uint32_t status;                     /* EGR_STATUS_* bit mask of the last launch                          */
     uint32_t bvh_depth;
+    uint32_t reserved;
 } egr_counters;
 
 #define EGR_STATUS_OK 0u
@@ -148,6 +149,7 @@ int egr_set_partition(egr_context *ctx, int rank, int world_size);
 
 /* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace. */
 int egr_get_counters(egr_context *ctx, egr_counters *out, void *hip_stream);
+int egr_reset_lifetime_counters(egr_context *ctx, void *hip_stream);
 
 /* Wall-clock of the last egr_raytrace / egr_update_bvh on the GPU (HIP events recorded on the launch stream
  * when timing is enabled). Returns milliseconds, <0 if not available. Synchronises on the end event. */

@@ -1,0 +1,9 @@
+import importlib, sys, os, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic"); ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
+W,H,N=1920,1080,1_000_000
+g=syn.make_scene(N,"trained",seed=0); cam=syn.default_camera(); pc=ren.GaussianParams(g)
+rt=ren.GaussianRaytracer(pc,W,H,ppll_forward_size=400_000_000,ppll_backward_size=300_000_000); m=rt.cuda_module
+camera=ren.camera_from_c2w(cam["origin"],cam["c2w"],cam["fov"])
+with torch.no_grad(): rt(camera)
+c=m.get_counters(); print("rays",c[0:3],"Hc",[c[3+i]/max(c[i],1) for i in range(3)],"Kc",[c[6+i]/max(c[i],1) for i in range(3)])
