@@ -1,0 +1,54 @@
+"""Multi-GPU decomposition of the hot path (nothing like it exists in the reference).
+
+The path shards over PIXELS: forward is independent per pixel, backward contributions sum over pixels. One
+process per GPU holds the full Gaussian set + BVH and traces the 16x16-pixel macro tiles whose index is congruent
+to its rank (round-robin = load balance between empty and dense image regions); the only exchange step is ONE
+all-reduce (sum) of the contiguous [22N] gradient buffer per iteration (RCCL over xGMI on the GPU box, gloo in the
+CPU tests). After it every rank holds identical gradients, so the replicated optimiser steps stay in lock-step.
+"""
+import numpy as np
+
+MACRO_TILE = 16  # must match EGR_MACRO_TILE in csrc/egr_internal.hpp
+WAVE_TILE = 8
+
+
+def macro_tiles(width, height):
+    return (width + MACRO_TILE - 1) // MACRO_TILE, (height + MACRO_TILE - 1) // MACRO_TILE
+
+
+def num_tasks_for_rank(width, height, rank, world):
+    """Python mirror of egr_num_tasks_for_rank (csrc/trace.hip): wave tiles (8x8) owned by `rank`."""
+    mtx, mty = macro_tiles(width, height)
+    M = mtx * mty
+    if rank >= M:
+        return 0
+    return 4 * ((M - rank + world - 1) // world)
+
+
+def owner_map(width, height, world):
+    """[H,W] int array: which rank traces each pixel (mirror of task_geom in csrc/egr_state.hpp)."""
+    mtx, _ = macro_tiles(width, height)
+    yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    return ((yy // MACRO_TILE) * mtx + (xx // MACRO_TILE)) % world
+
+
+def all_reduce_flat(flat, group=None):
+    """Sum a flat gradient buffer over ranks in place (one collective). No-op without an initialised process group."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+GRAD_LAYOUT = [("dL_drgb", 3), ("dL_dnormal", 3), ("dL_df0", 3), ("dL_droughness", 1), ("dL_dopacity", 1), ("dL_dscale", 3),
+               ("dL_dmean", 3), ("dL_drotation", 4), ("total_weight", 1)]  # tensor-major order inside grad_flat
+
+
+def split_flat(flat, n):
+    """Views of the [22N] buffer with the reference's per-tensor shapes (core/gaussians.h:15-24)."""
+    out, off = {}, 0
+    for name, c in GRAD_LAYOUT:
+        out[name] = flat[off:off + n * c].reshape(n, c)
+        off += n * c
+    return out
