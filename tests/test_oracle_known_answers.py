@@ -262,10 +262,14 @@ def test_cook_torrance_weight_formula(orc):
     assert np.abs(orc.cook_torrance_weight(N, V, L, r, f0) - ref).max() < 1e-5
 
 
-def test_downward_normal_yields_nan_like_reference(orc):
-    """ggx_brdf.h:163 builds the tangent from (0,0,1) whenever N.z < 0.999, including N=(0,0,-1): NaN. Kept."""
+def test_downward_normal_yields_nan_direction_but_zero_throughput(orc):
+    """ggx_brdf.h:163 builds the tangent from (0,0,1) whenever N.z < 0.999, including N=(0,0,-1): the sampled direction
+    is NaN. cook_torrance_weight then sees NaN dot products, which fmaxf(.,0) turns into 0 (CUDA maxNum semantics), so
+    the throughput is 0 (finite) and the dead bounce contributes nothing instead of poisoning the pixel."""
     L = orc.sample_cook_torrance([0, 0, -1.0], [0, 0.6, -0.8], 0.2, 0.3, 0.3)
     assert np.all(np.isnan(L))
+    w = orc.cook_torrance_weight([0, 0, -1.0], [0, 0.6, -0.8], L, 0.2, [0.04, 0.04, 0.04])
+    assert np.all(w == 0)
 
 
 # ------------------------------------------------------------------ structure
