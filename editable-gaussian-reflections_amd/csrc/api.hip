@@ -63,6 +63,10 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     c->device = device, c->width = width, c->height = height;
     c->fwd_capacity = ppll_forward_size > 0 ? ppll_forward_size : 1, c->bwd_capacity = ppll_backward_size > 0 ? ppll_backward_size : 1;
     if (const char *e = getenv("EGR_PACKET_MODE")) c->packet_mode = atoi(e);           // tuning knobs
+    if (const char *e = getenv("EGR_GROUP_LANES")) {
+        int g = atoi(e);
+        if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) c->group_lanes = (uint32_t)g;
+    }
     if (const char *e = getenv("EGR_PACKET_COS_MIN")) c->packet_cos_min = (float)atof(e);
     if (const char *e = getenv("EGR_PACKET_ORIGIN_MAX")) c->packet_origin_max = (float)atof(e);
     int rc = guarded(c, [&] {
@@ -220,8 +224,15 @@ int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, voi
     return guarded(c, [&] {
         EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
         size_t n = c->n_built;
-        if (M) EGR_HIP(hipMemcpy(M, c->inst_m, n * 12 * sizeof(float), hipMemcpyDeviceToHost));
-        if (W) EGR_HIP(hipMemcpy(W, c->inst_w, n * 12 * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> pos(n);
+        std::vector<float> tmp(n * 12);
+        EGR_HIP(hipMemcpy(pos.data(), c->pos_of_gid, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        auto unpermute = [&](const float4 *src, float *dst) { // records live at sorted positions; report them per gaussian id
+            EGR_HIP(hipMemcpy(tmp.data(), src, n * 12 * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; i++) memcpy(dst + 12 * i, tmp.data() + 12 * (size_t)pos[i], 12 * sizeof(float));
+        };
+        if (M) unpermute(c->inst_m, M);
+        if (W) unpermute(c->inst_w, W);
         if (aabb) EGR_HIP(hipMemcpy(aabb, c->aabb, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
     });
 }

@@ -19,6 +19,7 @@
 //     and M anyway), then issues the same 15/22 float atomics per hit as backward_pass.cu:210-220.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include "egr_state.hpp"
 
@@ -119,9 +120,31 @@ EGR_DI float4 load_f4_uniform(const float4 *base, uint32_t idx) { // idx must be
     return base[idx];
 #endif
 }
+EGR_DI uint4 load_u4_uniform(const uint4 *base, uint32_t idx) { // idx must be wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t egr_v4u __attribute__((ext_vector_type(4)));
+    const egr_v4u x = ((const __attribute__((address_space(4))) egr_v4u *)base)[idx];
+    return make_uint4(x[0], x[1], x[2], x[3]);
+#else
+    return base[idx];
+#endif
+}
+// Segment [tmin,tmax] vs a quantised node box, in the frame's cell coordinates (oq, invq = 1/(d*scale)).
+// Cell 0 / 65535 are the out-of-frame sentinels: -inf / +inf.
+EGR_DI bool qslab_hit(uint4 q, f3 oq, f3 invq, float tmin, float tmax) {
+    const uint32_t lx = q.x & 0xFFFFu, ly = q.x >> 16, lz = q.y & 0xFFFFu, hx = q.y >> 16, hy = q.z & 0xFFFFu, hz = q.z >> 16;
+    const float flx = lx == 0u ? -3.0e38f : (float)lx, fly = ly == 0u ? -3.0e38f : (float)ly, flz = lz == 0u ? -3.0e38f : (float)lz;
+    const float fhx = hx == 65535u ? 3.0e38f : (float)hx, fhy = hy == 65535u ? 3.0e38f : (float)hy, fhz = hz == 65535u ? 3.0e38f : (float)hz;
+    const float ax = (flx - oq.x) * invq.x, bx = (fhx - oq.x) * invq.x;
+    const float ay = (fly - oq.y) * invq.y, by = (fhy - oq.y) * invq.y;
+    const float az = (flz - oq.z) * invq.z, bz = (fhz - oq.z) * invq.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return t0 <= t1;
+}
 // OptiX's instance test restated: segment [tmin,tmax] of the object-space ray vs the unit cube.
 EGR_DI bool hits_unit_cube(f3 lo, f3 ld, float tmin, float tmax) {
-    f3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+    f3 inv = mk3(__builtin_amdgcn_rcpf(ld.x), __builtin_amdgcn_rcpf(ld.y), __builtin_amdgcn_rcpf(ld.z)); // v_rcp_f32, 1 ulp
     float t0 = tmin, t1 = tmax;
     bool ok = true;
 #define EGR_AXIS(c)                                                            \
@@ -168,10 +191,10 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v) {
     const egr_gaussians &g = v.g;
     float o = sigmoid_act(g.opacity[i]);
     float sigma = compute_scaling_factor(o, *v.cfg.alpha_threshold, *v.cfg.exp_power);
-    float4 *app = const_cast<float4 *>(v.app);
-    app[3 * i] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
-    app[3 * i + 1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
-    app[3 * i + 2] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
+    float4 *app = const_cast<float4 *>(v.app) + 3 * (size_t)v.pos_of_gid[i]; // stored at the sorted position
+    app[0] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
+    app[1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
+    app[2] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -181,7 +204,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     const int lane = threadIdx.x;
     float *__restrict__ keys = v.cand_keys + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
     float2 *__restrict__ vals = v.cand_vals + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
-    const float4 *__restrict__ nodes = v.nodes;
+    const uint4 *__restrict__ qnodes = v.qnodes;
     const float4 *__restrict__ app = v.app;
     const uint32_t END = v.num_nodes;
 
@@ -234,18 +257,51 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         // box the segment overlaps; phase B evaluates the queue. The queue lives in the lane's key column
         // (ids are overwritten by keys, write index <= read index).
         const bool ray_ok = active && finite3(ro) && finite3(rd); // NaN rays (ggx_brdf.h:163) hit nothing
-        const f3 inv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        uint32_t nleaf = 0;   // write cursor of the leaf queue (ids), >= cnt
+        // the ray in the quantisation frame of the tree: cell = (x - o) * s + 2, same t parametrisation
+        const f3 oq = mk3((ro.x - v.frame.ox) * v.frame.sx + 2.0f, (ro.y - v.frame.oy) * v.frame.sy + 2.0f, (ro.z - v.frame.oz) * v.frame.sz + 2.0f);
+        const f3 invq = mk3(1.0f / (rd.x * v.frame.sx), 1.0f / (rd.y * v.frame.sy), 1.0f / (rd.z * v.frame.sz));
+        uint32_t nq = 0;      // leaf clusters queued for evaluation (per-lane walk)
         uint32_t cnt = 0, traversed = 0;
         float full_T = 1.0f;
         bool overflow = false;
 #ifdef EGR_TRAVERSAL_STATS
         uint32_t st_visits = 0, st_leafhits = 0, st_inner = 0, st_outer = 0;
 #endif
-        // Tile coherence decides HOW phase A walks the tree. Coherent tiles (all primary tiles, mirror-like bounces)
-        // walk it as ONE packet: the node index is wave-uniform, the node is fetched with scalar loads (one request
-        // per wave instead of 64 divergent 16-B gathers, which is what bounds the per-lane walk: ~1 lane-load/clk/CU),
-        // every lane tests its own ray and a node is entered when ANY lane overlaps it. Incoherent tiles walk per lane.
+        // R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record.
+        // `prim` is the gaussian's SORTED POSITION (record index), not its id.
+        auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, const float4 &a2) {
+            const f3 lo = mk3(w0.x * ro.x + w0.y * ro.y + w0.z * ro.z + w0.w, w1.x * ro.x + w1.y * ro.y + w1.z * ro.z + w1.w,
+                              w2.x * ro.x + w2.y * ro.y + w2.z * ro.z + w2.w);
+            const f3 ld = mk3(w0.x * rd.x + w0.y * rd.y + w0.z * rd.z, w1.x * rd.x + w1.y * rd.y + w1.z * rd.z,
+                              w2.x * rd.x + w2.y * rd.y + w2.z * rd.z);
+            if (!hits_unit_cube(lo, ld, near_plane, far_plane)) return;
+            traversed++;                                    // shaders.cu:33
+            if (dot(lo, ld) > 0.0f) return;                 // :36
+            f3 dhat, u;
+            float t;
+            closest_point(lo, ld, dhat, t, u);              // :41-45
+            if (dot(u, u) > 1.0f) return;                   // :48-51
+            if (step != 0 && t < backfacing_max_dist) {     // :54-61 (world normal . object dir)
+                const uint32_t gid = v.gid_of_pos[prim];
+                f3 gn = mk3(v.g.normal[3 * gid], v.g.normal[3 * gid + 1], v.g.normal[3 * gid + 2]);
+                if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) return;
+            }
+            f3 x = u * a2.w;                                          // :64
+            float gaussval = eval_gaussian_sq(dot(x, x), exp_power);   // :65
+            float alpha = EGR_MAX_ALPHA * gaussval * a2.z;             // kernel.cu:14-16
+            full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
+            if (cnt < v.cand_cap) {
+                keys[(size_t)cnt * EGR_WAVE + lane] = t;
+                vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(prim));
+                cnt++;
+            } else {
+                overflow = true;
+            }
+        };
+        // Tile coherence decides HOW the tree is walked. Coherent tiles (all primary tiles, mirror-like bounces) walk
+        // it as ONE packet: the node index is wave-uniform, nodes / cluster members / transforms come through the
+        // scalar cache (one request per wave instead of 64 divergent gathers), every lane tests its own ray and a node
+        // is entered when ANY lane overlaps it. Incoherent tiles walk per lane.
         bool packet;
         {
             f3 dsum = mk3(ray_ok ? rd.x : 0.0f, ray_ok ? rd.y : 0.0f, ray_ok ? rd.z : 0.0f);
@@ -264,120 +320,77 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             packet = v.packet_mode == 2 ? (cmin >= v.packet_cos_min && omax <= v.packet_origin_max) : (v.packet_mode == 1 && step == 0);
             packet = __builtin_amdgcn_readfirstlane(packet ? 1 : 0) != 0;
         }
-        uint32_t node = ray_ok ? 0u : END;
-        uint32_t unode = 0u; // wave-uniform cursor of the packet walk
-        for (;;) {
-            // ---- phase A: queue the ids of the leaves whose box this lane's segment overlaps ----
-            if (packet) {
-                // fused walk + evaluation: the leaf's transform and live record are wave-uniform too, so they come
-                // through the scalar cache as well and every lane whose segment overlaps the leaf box evaluates its
-                // own ray against them. No per-lane gathers at all on this path.
-                while (unode < END) {
-                    const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)unode);
-                    float4 n0, n1;
-                    load_node_uniform(nodes, un, n0, n1); // (tried: 8-node window via one coalesced vector load + v_readlane; slower)
-                    const bool hit = ray_ok && slab_hit(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), ro, inv, near_plane, far_plane);
-                    const uint32_t skip = f2u(n0.w), p = f2u(n1.w);
-                    const bool any = __ballot(hit) != 0ull;
+        if (packet) {
+            uint32_t unode = 0u; // wave-uniform cursor
+            while (unode < END) {
+                const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)unode);
+                const uint4 qn = load_u4_uniform(qnodes, un);
+                const bool hit = ray_ok && qslab_hit(qn, oq, invq, near_plane, far_plane);
+                const bool any = __ballot(hit) != 0ull;
+                const bool leaf = (qn.w & EGR_LEAF_FLAG) != 0u;
 #ifdef EGR_TRAVERSAL_STATS
-                    st_visits += hit ? 1u : 0u;
-                    st_inner += (lane == 0);
-                    st_leafhits += (hit && p != EGR_INTERNAL_NODE) ? 1u : 0u;
-                    st_outer += (lane == 0 && any && p != EGR_INTERNAL_NODE);
+                st_visits += hit ? 1u : 0u;
+                st_inner += (lane == 0);
+                st_leafhits += (hit && leaf) ? 1u : 0u;
+                st_outer += (lane == 0 && any && leaf);
 #endif
-                    if (any && p != EGR_INTERNAL_NODE) {
+                if (any && leaf) {
+                    const uint32_t first = EGR_CLUSTER * (qn.w & ~EGR_LEAF_FLAG); // members = sorted positions, contiguous records
+#pragma unroll
+                    for (int k = 0; k < EGR_CLUSTER; k++) {
+                        const uint32_t p = first + k;
+                        if (p >= v.n) continue; // uniform
                         const float4 w0 = load_f4_uniform(v.inst_w, 3 * p), w1 = load_f4_uniform(v.inst_w, 3 * p + 1), w2 = load_f4_uniform(v.inst_w, 3 * p + 2);
                         const float4 a2 = load_f4_uniform(app, 3 * p + 2);
-                        if (hit) {
-                            const f3 lo = mk3(w0.x * ro.x + w0.y * ro.y + w0.z * ro.z + w0.w, w1.x * ro.x + w1.y * ro.y + w1.z * ro.z + w1.w,
-                                              w2.x * ro.x + w2.y * ro.y + w2.z * ro.z + w2.w);
-                            const f3 ld = mk3(w0.x * rd.x + w0.y * rd.y + w0.z * rd.z, w1.x * rd.x + w1.y * rd.y + w1.z * rd.z,
-                                              w2.x * rd.x + w2.y * rd.y + w2.z * rd.z);
-                            if (hits_unit_cube(lo, ld, near_plane, far_plane)) {
-                                traversed++;                                    // shaders.cu:33
-                                if (!(dot(lo, ld) > 0.0f)) {                    // :36
-                                    f3 dhat, u;
-                                    float t;
-                                    closest_point(lo, ld, dhat, t, u);          // :41-45
-                                    bool accept = !(dot(u, u) > 1.0f);          // :48-51
-                                    if (accept && step != 0 && t < backfacing_max_dist) { // :54-61
-                                        f3 gn = mk3(v.g.normal[3 * p], v.g.normal[3 * p + 1], v.g.normal[3 * p + 2]);
-                                        if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) accept = false;
-                                    }
-                                    if (accept) {
-                                        f3 x = u * a2.w;                                          // :64
-                                        float gaussval = eval_gaussian_sq(dot(x, x), exp_power);   // :65
-                                        float alpha = EGR_MAX_ALPHA * gaussval * a2.z;             // kernel.cu:14-16
-                                        full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
-                                        if (cnt < v.cand_cap) {
-                                            keys[(size_t)cnt * EGR_WAVE + lane] = t;
-                                            vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(p));
-                                            cnt++;
-                                        } else {
-                                            overflow = true;
-                                        }
-                                    }
-                                }
-                            }
-                        }
+                        if (hit) evaluate(p, w0, w1, w2, a2);
                     }
-                    unode = (any && p == EGR_INTERNAL_NODE) ? un + 1 : skip;
                 }
-                node = END;
-                nleaf = cnt;
-            } else {
-                while (node < END && nleaf < v.cand_cap) {
-                    float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
-                    bool hit = slab_hit(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), ro, inv, near_plane, far_plane);
-                    uint32_t skip = f2u(n0.w), p = f2u(n1.w);
+                unode = (any && !leaf) ? un + 1 : (leaf ? un + 1 : qn.w);
+            }
+        } else {
+            uint32_t *__restrict__ queue = v.cand_queue + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
+            const bool grp_ok = v.group_lanes <= 1u ? ray_ok : (((__ballot(ray_ok) >> ((uint32_t)lane & ~(v.group_lanes - 1u))) & (v.group_lanes >= 64u ? ~0ull : ((1ull << v.group_lanes) - 1ull))) != 0ull);
+            uint32_t node = grp_ok ? 0u : END;
+            for (;;) {
+                // ---- phase A: queue the leaf clusters whose box the segment of ANY lane of this lane's group overlaps.
+                // Lanes are grouped in runs of G (= v.group_lanes: 1 = fully per-lane ... 64 = whole-wave packet); a group
+                // walks the tree in lockstep, so its G node fetches hit ONE cache line instead of G: the per-lane walk is
+                // bound by L1 line fills (every divergent 16-B gather pulls a 128-B line), not by instructions.
+                const uint32_t gsh = (uint32_t)lane & ~(v.group_lanes - 1u);
+                const unsigned long long gmask = v.group_lanes >= 64u ? ~0ull : ((1ull << v.group_lanes) - 1ull);
+                while (node < END && nq < v.cand_cap) {
+                    const uint4 qn = qnodes[node];
+                    const bool hit = ray_ok && qslab_hit(qn, oq, invq, near_plane, far_plane);
+                    const bool ghit = ((__ballot(hit) >> gsh) & gmask) != 0ull;
+                    const bool leaf = (qn.w & EGR_LEAF_FLAG) != 0u;
 #ifdef EGR_TRAVERSAL_STATS
                     st_visits++;
                     if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
 #endif
-                    if (hit && p != EGR_INTERNAL_NODE) keys[(size_t)nleaf * EGR_WAVE + lane] = u2f(p), nleaf++;
-                    node = (hit && p == EGR_INTERNAL_NODE) ? node + 1 : skip;
+                    if (ghit && leaf) queue[(size_t)nq * EGR_WAVE + lane] = qn.w & ~EGR_LEAF_FLAG, nq++;
+                    node = (leaf || ghit) ? node + 1 : qn.w;
                 }
-            }
 #ifdef EGR_TRAVERSAL_STATS
-            st_leafhits += nleaf - cnt;
+                st_leafhits += nq;
 #endif
-            // ---- phase B: evaluate the queued leaves [cnt, nleaf), compacting accepted hits to [.., cnt) ----
-            const uint32_t qbeg = cnt;
-            for (uint32_t q = qbeg; q < nleaf; q++) {
-                const uint32_t prim = f2u(keys[(size_t)q * EGR_WAVE + lane]);
+                // ---- phase B: evaluate the members of the queued clusters ----
+                for (uint32_t q = 0; q < nq; q++) {
+                    const uint32_t first = EGR_CLUSTER * queue[(size_t)q * EGR_WAVE + lane];
 #ifdef EGR_TRAVERSAL_STATS
-                st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
+                    st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
 #endif
-                f3 lo, ld;
-                object_ray(v.inst_w, prim, ro, rd, lo, ld);
-                if (!hits_unit_cube(lo, ld, near_plane, far_plane)) continue;
-                traversed++;                                        // shaders.cu:33
-                if (dot(lo, ld) > 0.0f) continue;                   // :36
-                f3 dhat, u;
-                float t;
-                closest_point(lo, ld, dhat, t, u);                  // :41-45
-                if (dot(u, u) > 1.0f) continue;                     // :48-51
-                if (step != 0 && t < backfacing_max_dist) {         // :54-61 (world normal . object dir)
-                    f3 gn = mk3(v.g.normal[3 * prim], v.g.normal[3 * prim + 1], v.g.normal[3 * prim + 2]);
-                    if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) continue;
+#pragma unroll
+                    for (int k = 0; k < EGR_CLUSTER; k++) {
+                        const uint32_t p = first + k;
+                        if (p >= v.n) continue;
+                        const float4 w0 = v.inst_w[3 * p], w1 = v.inst_w[3 * p + 1], w2 = v.inst_w[3 * p + 2];
+                        const float4 a2 = app[3 * p + 2];
+                        if (ray_ok) evaluate(p, w0, w1, w2, a2);
+                    }
                 }
-                float4 a2 = app[3 * prim + 2]; // (f0.z, roughness, opacity, sigma)
-                f3 x = u * a2.w;                                     // :64
-                float gaussval = eval_gaussian_sq(dot(x, x), exp_power); // :65
-                float alpha = EGR_MAX_ALPHA * gaussval * a2.z;       // kernel.cu:14-16
-                full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
-                keys[(size_t)cnt * EGR_WAVE + lane] = t;             // cnt <= q: never overtakes the read cursor
-                vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(prim));
-                cnt++;
+                nq = 0;
+                if (__ballot(node < END) == 0ull) break;
             }
-            nleaf = cnt; // the queue restarts right behind the accepted hits
-            const bool more = packet ? (unode < END) : (node < END);
-            if (more && cnt >= v.cand_cap) { // accepted hits alone fill the capacity: drop the rest, raise the flag
-                overflow = true;
-                node = END;
-                if (packet) unode = END;
-            }
-            if (__ballot(packet ? (unode < END) : (node < END)) == 0ull) break;
         }
 
 #ifdef EGR_TRAVERSAL_STATS
@@ -440,8 +453,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                     k_prev = bi;
                     float2 av = vals[(size_t)bi * EGR_WAVE + lane];
                     float alpha = av.x;
-                    uint32_t gid = f2u(av.y);
-                    float4 a0 = app[3 * gid], a1 = app[3 * gid + 1], a2 = app[3 * gid + 2];
+                    uint32_t pos = f2u(av.y); // record index (sorted position)
+                    float4 a0 = app[3 * pos], a1 = app[3 * pos + 1], a2 = app[3 * pos + 2];
                     float next_T = T * (1.0f - alpha);       // :108
                     float weight = T - next_T;               // :109
                     c_rgb = c_rgb + mk3(a0.x, a0.y, a0.z) * weight;
@@ -453,7 +466,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                     nhits++;
                     if (GRADS && recording)
                         v.hit_arena[((size_t)cur_block * (EGR_HIT_BLOCK_ROWS + 1) + 1 + (it % EGR_HIT_BLOCK_ROWS)) * EGR_WAVE + lane] =
-                            make_float4(u2f(gid), best, alpha, T);
+                            make_float4(u2f(pos), best, alpha, T);
                     if (T < transmittance_threshold || nhits >= EGR_MAX_COMPOSITED_PER_RAY) running = false; // :131-134, :55
                 }
             }
@@ -607,15 +620,16 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                 if (it >= max_hits) continue;
                 if (it < nhits) {
                     const float4 rec = rows[(size_t)(1 + row) * EGR_WAVE + lane];
-                    const uint32_t gid = f2u(rec.x);
+                    const uint32_t pos = f2u(rec.x);          // record index (sorted position)
+                    const uint32_t gid = v.gid_of_pos[pos];   // the caller's gaussian id (parameter / gradient index)
                     const float distance = rec.y, alpha = rec.z, transmittance = rec.w;
-                    const float4 a0 = v.app[3 * gid], a1 = v.app[3 * gid + 1], a2 = v.app[3 * gid + 2];
+                    const float4 a0 = v.app[3 * pos], a1 = v.app[3 * pos + 1], a2 = v.app[3 * pos + 2];
                     const f3 g_rgb = mk3(a0.x, a0.y, a0.z);
                     const float opacity = a2.z, scaling_factor = a2.w;
                     // recompute the local hit exactly as the forward did
                     f3 lo, ld, dhat, u;
                     float t_unused;
-                    object_ray(v.inst_w, gid, ro, rd, lo, ld);
+                    object_ray(v.inst_w, pos, ro, rd, lo, ld);
                     closest_point(lo, ld, dhat, t_unused, u);
                     const f3 local_hit = u * scaling_factor;
                     const float sq_norm = dot(local_hit, local_hit);
@@ -659,7 +673,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     const float dL_dgaussval = EGR_MAX_ALPHA * dL_dalpha * opacity; // :155-158
                     const float dL_dsq_norm = gaussval * pow_exp_m1(sq_norm, exp_power);
                     const f3 dL_dx_local = (-local_hit * dL_dsq_norm) * dL_dgaussval;
-                    const float4 W0 = v.inst_w[3 * gid], W1 = v.inst_w[3 * gid + 1], W2 = v.inst_w[3 * gid + 2];
+                    const float4 W0 = v.inst_w[3 * pos], W1 = v.inst_w[3 * pos + 1], W2 = v.inst_w[3 * pos + 2];
                     const f3 dL_dx_world = mk3(dot(mk3(W0.x, W1.x, W2.x), dL_dx_local), dot(mk3(W0.y, W1.y, W2.y), dL_dx_local),
                                                dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
                     const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
@@ -667,7 +681,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     const f3 scaling = mk3(expf(g.scale[3 * gid]), expf(g.scale[3 * gid + 1]), expf(g.scale[3 * gid + 2]));
                     const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
                                        scaling.z * scaling_factor + eps_scale_grad);
-                    const float4 M0 = v.inst_m[3 * gid], M1 = v.inst_m[3 * gid + 1], M2 = v.inst_m[3 * gid + 2];
+                    const float4 M0 = v.inst_m[3 * pos], M1 = v.inst_m[3 * pos + 1], M2 = v.inst_m[3 * pos + 2];
                     const f3 rot_0 = mk3(M0.x, M0.y, M0.z) / den, rot_1 = mk3(M1.x, M1.y, M1.z) / den, rot_2 = mk3(M2.x, M2.y, M2.z) / den; // :178-180
                     const f3 d_scale = (dl2w0 * rot_0 + dl2w1 * rot_1 + dl2w2 * rot_2) * scaling; // :181-182
                     const f3 dr0 = dl2w0 * scaling, dr1 = dl2w1 * scaling, dr2 = dl2w2 * scaling; // :185-187
@@ -795,7 +809,7 @@ uint32_t egr_num_tasks_for_rank(const egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
+    dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
     if (c->control_host) (void)hipHostFree(c->control_host);
     c->control_host = nullptr;
 }
@@ -809,14 +823,16 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, k_forward<true>, EGR_WAVE, 0));
     EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_n, k_forward<false>, EGR_WAVE, 0));
     int per_cu = std::max(1, std::min(32, std::max(per_cu_g, per_cu_n)));
+    if (const char *e = getenv("EGR_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // tuning knob
     uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
     // forward budget: the reference's ppll_forward_size entries x 36 B, spent on (key 4 B + value 8 B) x 64 lanes x cap per slot
     double fwd_bytes = (double)c->fwd_capacity * 36.0;
-    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * EGR_WAVE * 12.0));
+    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * EGR_WAVE * 16.0)); // key 4 + value 8 + queue 4 bytes
     c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384);
     EGR_HIP(hipMalloc((void **)&c->cand_keys, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
     EGR_HIP(hipMalloc((void **)&c->cand_vals, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
+    EGR_HIP(hipMalloc((void **)&c->cand_queue, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
     double bwd_bytes = (double)c->bwd_capacity * 36.0;
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
@@ -836,15 +852,16 @@ DeviceView egr_make_view(const egr_context *c) {
     v.tiles_x = (c->width + EGR_TILE - 1) / EGR_TILE, v.tiles_y = (c->height + EGR_TILE - 1) / EGR_TILE;
     v.num_pixels = (uint32_t)c->width * (uint32_t)c->height;
     v.n = c->g.count;
-    v.num_nodes = c->n_built ? 2 * c->n_built - 1 : 0;
+    v.num_nodes = c->n_built ? 2 * c->n_clusters - 1 : 0;
     v.rank = c->rank, v.world = c->world;
     v.num_tasks = egr_num_tasks_for_rank(c);
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
-    v.nodes = c->nodes, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
-    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
+    v.qnodes = c->qnodes, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
+    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
+    v.group_lanes = c->group_lanes;
     return v;
 }
 
