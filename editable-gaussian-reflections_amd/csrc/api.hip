@@ -112,7 +112,10 @@ int egr_set_gaussians(egr_context *c, const egr_gaussians *g) {
 int egr_set_partition(egr_context *c, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return 1;
     c->rank = rank, c->world = world;
-    return 0;
+    return guarded(c, [&] {
+        EGR_HIP(hipDeviceSynchronize());
+        egr_build_task_order(c);
+    });
 }
 
 static int require_ready(egr_context *c, bool need_bvh) {

@@ -50,6 +50,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     // partition
     int rank, world;
     uint32_t num_tasks;  // wave tiles owned by this rank
+    const uint32_t *task_macro; // [num_tasks/4] macro tile index of each group of 4 tasks
     egr_gaussians g;
     egr_config cfg;
     egr_camera cam;
@@ -146,6 +147,7 @@ struct egr_context {
     float *state = nullptr;
     uint32_t state_stride = 0;
     uint32_t num_tasks_total = 0; // wave tiles in the whole image
+    uint32_t *task_macro = nullptr; // device table, rebuilt by egr_build_task_order when the partition changes
     uint32_t *control = nullptr;
     uint32_t *control_host = nullptr; // pinned
     // timing
@@ -171,6 +173,7 @@ void egr_trace_alloc(egr_context *c);
 void egr_trace_free(egr_context *c);
 void egr_trace_launch(egr_context *c, bool grads, hipStream_t s);
 uint32_t egr_num_tasks_for_rank(const egr_context *c);
+void egr_build_task_order(egr_context *c);
 DeviceView egr_make_view(const egr_context *c);
 // timing helpers (api.hip)
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s);

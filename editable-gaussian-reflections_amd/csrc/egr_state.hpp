@@ -28,11 +28,13 @@ struct TaskGeom {
     uint32_t pixel_id;
     bool inside;
 };
-// task -> wave tile -> pixel. Tasks enumerate the 16x16 macro tiles owned by this rank (round-robin), 4 wave
-// tiles each, so that neighbouring tasks share BVH nodes in cache.
+// task -> wave tile -> pixel. Tasks enumerate the 16x16 macro tiles owned by this rank (every world-th tile), 4 wave
+// tiles each, in the order of v.task_macro: the task range is cut into 8 contiguous chunks (one per XCD queue), each
+// chunk is a compact 2-D block of the image walked along a Z-curve, so the waves resident on one XCD at any time
+// cover a compact patch (their rays meet the same BVH nodes / records -> per-XCD L2 hits, not fabric traffic).
 EGR_DI TaskGeom task_geom(const DeviceView &v, uint32_t task, int lane) {
     uint32_t mtx = (uint32_t)(v.width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
-    uint32_t m = (task >> 2) * (uint32_t)v.world + (uint32_t)v.rank;
+    uint32_t m = v.task_macro[task >> 2]; // this rank's macro tiles in cache-friendly order (see egr_build_task_order)
     uint32_t sub = task & 3u;
     int tx = (int)(m % mtx) * 2 + (int)(sub & 1u), ty = (int)(m / mtx) * 2 + (int)(sub >> 1);
     TaskGeom g;

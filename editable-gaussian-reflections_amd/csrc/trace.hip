@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "egr_state.hpp"
 
@@ -808,8 +810,30 @@ uint32_t egr_num_tasks_for_rank(const egr_context *c) {
     return 4u * ((M - (uint32_t)c->rank + (uint32_t)c->world - 1) / (uint32_t)c->world);
 }
 
+// Order of this rank's macro tiles: sort by (XCD chunk block, Z-curve inside the block). The 8 chunks that
+// wave_next_task hands to the 8 XCD queues are equal slices of this order, so each is a compact image block.
+void egr_build_task_order(egr_context *c) {
+    const uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
+    auto part1by1 = [](uint32_t x) {
+        x &= 0xFFFFu;
+        x = (x | (x << 8)) & 0x00FF00FFu, x = (x | (x << 4)) & 0x0F0F0F0Fu, x = (x | (x << 2)) & 0x33333333u, x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> keyed;
+    for (uint32_t m = (uint32_t)c->rank; m < mtx * mty; m += (uint32_t)c->world) {
+        const uint32_t mx = m % mtx, my = m / mtx;
+        const uint32_t bx = std::min(3u, mx * 4u / mtx), by = std::min(1u, my * 2u / mty); // 4 x 2 blocks of the image
+        const uint64_t key = ((uint64_t)(by * 4u + bx) << 32) | (part1by1(mx) | (part1by1(my) << 1));
+        keyed.push_back({key, m});
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> order(std::max<size_t>(keyed.size(), 1), 0u);
+    for (size_t i = 0; i < keyed.size(); i++) order[i] = keyed[i].second;
+    EGR_HIP(hipMemcpy(c->task_macro, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
 void egr_trace_free(egr_context *c) {
-    dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
+    dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
     if (c->control_host) (void)hipHostFree(c->control_host);
     c->control_host = nullptr;
 }
@@ -844,6 +868,8 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->control, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipMemset(c->control, 0, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipHostMalloc((void **)&c->control_host, CW_COUNT * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->task_macro, std::max<size_t>(c->num_tasks_total / 4, 1) * sizeof(uint32_t)));
+    egr_build_task_order(c);
 }
 
 DeviceView egr_make_view(const egr_context *c) {
@@ -855,6 +881,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.num_nodes = c->n_built ? 2 * c->n_clusters - 1 : 0;
     v.rank = c->rank, v.world = c->world;
     v.num_tasks = egr_num_tasks_for_rank(c);
+    v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.qnodes = c->qnodes, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;

@@ -1,0 +1,15 @@
+"""One full-size training iteration (1080p, 1M gaussians) for rocprofv3 --pmc passes (kept minimal: PMC runs are slow)."""
+import importlib, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic"); ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
+W, H, N = 1920, 1080, 1_000_000
+g = syn.make_scene(N, "trained", seed=0); cam = syn.default_camera(); tg = syn.make_targets(W, H)
+pc = ren.GaussianParams(g)
+rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000)
+images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()}
+camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **images)
+for _ in range(int(os.environ.get("ITERS", 1))):
+    rt.zero_grad()
+    ren.render(camera, rt)
+torch.cuda.synchronize()
+print("counters", rt.cuda_module.get_counters())

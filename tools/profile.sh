@@ -1,19 +1,16 @@
 #!/bin/bash
-# Usage (on the GPU box): tools/profile.sh <tag> [bench args...]
-# Collects: kernel-trace stats + separate PMC passes (never combined with other trace domains) into gpurun_out/<tag>/
+# Usage (on the GPU box): tools/profile.sh <tag>
+# 1) rocprofv3 --kernel-trace --stats of the default bench command; 2) separate, time-boxed --pmc passes
+#    (FETCH_SIZE / WRITE_SIZE / L2 hit) on ONE iteration. PMC is never combined with other trace domains.
 set -u
-TAG=${1:-prof}; shift || true
+TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --profile-steps 0 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+tail -1 $OUT/bench_under_rocprof.log > $OUT/bench_line.json
 i=0
-for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
-           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" \
-           "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TCP_TOTAL_CACHE_ACCESSES" \
-           "TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_LATENCY TCP_TOTAL_READ" \
-           "TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ" "FETCH_SIZE" "WRITE_SIZE"; do
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_REQ" "TCP_TCC_READ_REQ TCP_TOTAL_CACHE_ACCESSES TCP_TOTAL_READ"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc$i -o p -- python bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  ( time timeout 420 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc$i -o p -- python tools/pmc_run.py ) > $OUT/pmc$i.log 2>&1
 done
 find $OUT -name "*.csv" | head -40
