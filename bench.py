@@ -152,8 +152,20 @@ def main():
                 cands[f"backward_step{s}"] = algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank)
         dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
         achieved = cands[dom] / (kern[dom] * 1e-3) / 1e9
+        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes of this command (profiles/<round>/
+        # pmc_summary.json, collected by tools/profile.sh in separate FETCH_SIZE / WRITE_SIZE passes; units of KiB;
+        # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md). bench.py cannot run the profiler itself.
+        traffic = None
+        try:
+            rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_summary.json")))
+            if rounds and world == 1 and not a.forward_only:
+                pm = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "pmc_summary.json"))).get(dom)
+                if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                "traffic": None, "avg_kernel_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": cands[dom],
+                "traffic": traffic, "avg_kernel_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": cands[dom],
                 "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
                 "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
                 "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
