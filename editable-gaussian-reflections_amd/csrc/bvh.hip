@@ -3,17 +3,15 @@
 //   OptiX TLAS build / refit                 (optix/bvh_wrapper.h:32-59,118-157; closed source)
 //
 // Design (MI355X-first, not a translation of OptiX instancing):
-//   * per-lane traversal is bound by the texture addresser (one divergent 16-B gather per lane per clock), so a
-//     node is ONE 16-byte load: the box is quantised to 16 bits per coordinate in a per-build frame (conservative:
-//     one extra cell each side; 0 / 65535 decode to -inf / +inf so boxes that drift out of the frame between
-//     rebuilds stay correct), plus a 32-bit link;
-//   * leaves are CLUSTERS of 4 Morton-consecutive Gaussians: 4x fewer tree nodes, and the members are tested with
-//     the exact object-space cube test directly (their loose world AABBs are never fetched during traversal);
-//   * nodes are stored in DFS pre-order with a skip index ("threaded" BVH), so traversal needs NO stack:
-//     hit -> node+1, miss -> skip, after a leaf -> node+1;
-//   * topology from 63-bit Morton codes of the Gaussian means (Karras 2012), built only on rebuild;
-//   * the per-iteration refit is atomics-free and fence-free: internal nodes are bucketed by depth at build
-//     time and refitted deepest-first, one launch per depth (kernel boundaries provide the ordering the
+//   * the incoherent (bounce) walk is bound by cache-line fills, not instructions: every divergent 16-B gather pulls
+//     a whole 128-B line (PMC, profiles/r1: L1 hit 56 %, L2 hit 63 %, ~10x re-fetch). So a node IS one line:
+//     8 children x 16 B = 128 B, aligned. A child slot = box quantised to 16 bits per coordinate in a per-build frame
+//     (conservative: one extra cell each side; cells 0 / 65535 decode to -inf / +inf so boxes that drift out of the
+//     frame between rebuilds stay correct) + 32-bit link (leaf: record index, internal: child node, or empty);
+//   * topology: binary LBVH from 63-bit Morton codes of the Gaussian means (Karras 2012), collapsed to 8-wide nodes
+//     level by level (always expanding the child with the most leaves); built only on rebuild;
+//   * the per-iteration refit is atomics-free and fence-free: wide nodes of one level occupy a contiguous index
+//     range and are refitted deepest level first, one launch per level (kernel boundaries provide the ordering the
 //     non-coherent per-XCD L2s would otherwise need agent-scope fences for).
 #include <string.h>
 
@@ -154,11 +152,6 @@ __global__ void __launch_bounds__(BS) k_morton(uint32_t n, const float *__restri
     keys[i] = key;
     vals[i] = i;
 }
-// clusters: EGR_CLUSTER Morton-consecutive gaussians (sorted positions [C*j, C*j+C)); cluster key = key of its first member
-__global__ void __launch_bounds__(BS) k_clusters(uint32_t n, uint32_t nc, const uint64_t *__restrict__ keys_sorted, uint64_t *__restrict__ ckeys) {
-    uint32_t j = blockIdx.x * BS + threadIdx.x;
-    if (j < nc) ckeys[j] = keys_sorted[EGR_CLUSTER * j];
-}
 __global__ void __launch_bounds__(BS) k_inverse_perm(uint32_t n, const uint32_t *__restrict__ gid_of_pos, uint32_t *__restrict__ pos_of_gid) {
     uint32_t p = blockIdx.x * BS + threadIdx.x;
     if (p < n) pos_of_gid[gid_of_pos[p]] = p;
@@ -205,41 +198,54 @@ __global__ void __launch_bounds__(BS) k_karras(int n, const uint64_t *__restrict
     if (i == 0) parent[0] = -1;
 }
 
-// Pre-order position of every node: pre = 2*first + (#left turns on the root path); skip = pre + 2*leaves - 1.
-__global__ void __launch_bounds__(BS) k_preorder(int n, const int32_t *__restrict__ left, const int32_t *__restrict__ parent,
-                                                 const uint32_t *__restrict__ first, const uint32_t *__restrict__ last,
-                                                 uint4 *__restrict__ qnodes, uint32_t *__restrict__ leaf_pre,
-                                                 uint32_t *__restrict__ node_depth, uint32_t *__restrict__ hist) {
-    int id = blockIdx.x * BS + threadIdx.x;
-    if (id >= 2 * n - 1) return;
-    bool leaf = id >= n - 1;
-    uint32_t f = leaf ? (uint32_t)(id - (n - 1)) : first[id];
-    uint32_t leaves = leaf ? 1u : last[id] - first[id] + 1u;
-    uint32_t turns = 0, depth = 0;
-    int x = id;
-    while (true) {
-        int p = (n == 1) ? -1 : parent[x];
-        if (p < 0) break;
-        turns += (left[p] == x) ? 1u : 0u;
-        depth++;
-        x = p;
+// ---------------------------------------------------------------------------------------------------------
+// Collapse of the binary tree into 8-wide nodes, one level of the wide tree per launch.
+// frontier_in: binary internal ids that ARE wide nodes of this level (their wide index is wide_of[id]).
+// Children = the binary node's two children, then repeatedly the internal child with the most leaves is replaced by
+// its own two children until there are 8 (or only leaves). Internal children become wide nodes of the next level.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, const uint32_t *__restrict__ frontier_in,
+                                                       const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                                                       const uint32_t *__restrict__ first, const uint32_t *__restrict__ last,
+                                                       uint32_t *__restrict__ wide_of, uint32_t *__restrict__ counters, // [0] = #wide nodes, [1] = next frontier size
+                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes) {
+    uint32_t t = blockIdx.x * BS + threadIdx.x;
+    if (t >= count) return;
+    const int b = (int)frontier_in[t];
+    const uint32_t w = wide_of[b];
+    int child[EGR_WIDTH];
+    int nchild = 2;
+    child[0] = left[b], child[1] = right[b];
+    auto leaves_of = [&](int id) -> uint32_t { return id >= n - 1 ? 1u : last[id] - first[id] + 1u; };
+    while (nchild < EGR_WIDTH) {
+        int best = -1;
+        uint32_t best_leaves = 1;
+        for (int k = 0; k < nchild; k++) {
+            uint32_t l = leaves_of(child[k]);
+            if (l > best_leaves) best_leaves = l, best = k;
+        }
+        if (best < 0) break; // only leaves left
+        const int id = child[best];
+        child[best] = left[id]; // keep the Morton order of the children: insert the right child just after
+        for (int k = nchild; k > best + 1; k--) child[k] = child[k - 1];
+        child[best + 1] = right[id];
+        nchild++;
     }
-    uint32_t pre = 2u * f + turns;
-    uint32_t skip = pre + 2u * leaves - 1u;
-    uint32_t link = leaf ? (EGR_LEAF_FLAG | (uint32_t)(id - (n - 1))) : skip; // leaf payload finalised in k_leaf_boxes
-    qnodes[pre] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, link); // empty box: lo = 65535, hi = 0
-    node_depth[pre] = leaf ? 0xFFFFFFFFu : depth;
-    if (leaf) leaf_pre[id - (n - 1)] = pre;
-    else atomicAdd(&hist[min(depth, (uint32_t)EGR_MAX_DEPTH_BINS - 1)], 1u);
-}
-__global__ void __launch_bounds__(BS) k_scatter_depth(uint32_t num_nodes, const uint32_t *__restrict__ node_depth,
-                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
-    uint32_t p = blockIdx.x * BS + threadIdx.x;
-    if (p >= num_nodes) return;
-    uint32_t d = node_depth[p];
-    if (d == 0xFFFFFFFFu) return;
-    uint32_t pos = atomicAdd(&cursor[min(d, (uint32_t)EGR_MAX_DEPTH_BINS - 1)], 1u);
-    order[pos] = p;
+    for (int k = 0; k < EGR_WIDTH; k++) {
+        uint32_t link = EGR_EMPTY_SLOT;
+        if (k < nchild) {
+            const int id = child[k];
+            if (id >= n - 1) {
+                link = EGR_LEAF_FLAG | (uint32_t)(id - (n - 1)); // leaf: sorted position of the gaussian
+            } else {
+                const uint32_t idx = atomicAdd(&counters[0], 1u);
+                wide_of[id] = idx;
+                frontier_out[atomicAdd(&counters[1], 1u)] = (uint32_t)id;
+                link = idx;
+            }
+        }
+        wnodes[(size_t)w * EGR_WIDTH + k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, link); // empty box until refit
+    }
 }
 
 // ---- 16-bit box quantisation in the build frame. u = (x - origin) * scale + 2 (cells); lo rounds down one extra
@@ -252,60 +258,41 @@ __device__ __forceinline__ uint32_t quant_hi(float x, float o, float s) {
     float u = (x - o) * s + 2.0f;
     return (u <= 65533.0f) ? (uint32_t)fmaxf(ceilf(u) + 1.0f, 1.0f) : 65535u;
 }
+__device__ __forceinline__ void unpack_box(uint4 q, uint32_t lo[3], uint32_t hi[3]) {
+    lo[0] = q.x & 0xFFFFu, lo[1] = q.x >> 16, lo[2] = q.y & 0xFFFFu, hi[0] = q.y >> 16, hi[1] = q.z & 0xFFFFu, hi[2] = q.z >> 16;
+}
 __device__ __forceinline__ uint4 pack_box(const uint32_t lo[3], const uint32_t hi[3], uint32_t link) {
     return make_uint4(lo[0] | (lo[1] << 16), lo[2] | (hi[0] << 16), hi[1] | (hi[2] << 16), link);
 }
-__device__ __forceinline__ uint4 union_box(uint4 a, uint4 b, uint32_t link) {
-    uint32_t lo[3] = {min(a.x & 0xFFFFu, b.x & 0xFFFFu), min(a.x >> 16, b.x >> 16), min(a.y & 0xFFFFu, b.y & 0xFFFFu)};
-    uint32_t hi[3] = {max(a.y >> 16, b.y >> 16), max(a.z & 0xFFFFu, b.z & 0xFFFFu), max(a.z >> 16, b.z >> 16)};
-    return pack_box(lo, hi, link);
-}
-__global__ void __launch_bounds__(BS) k_leaf_boxes(uint32_t n, uint32_t nc, const float *__restrict__ aabb, const uint32_t *__restrict__ gid_of_pos,
-                                                   const uint32_t *__restrict__ leaf_pre, BvhFrame fr, uint4 *__restrict__ qnodes) {
-    uint32_t j = blockIdx.x * BS + threadIdx.x;
-    if (j >= nc) return;
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+// One level of the wide tree: every child slot's box. Leaf slot: the gaussian's (padded) world box. Internal slot: the
+// union of the child node's 8 slot boxes - the child lives in a deeper level that an earlier launch already refitted.
+__global__ void __launch_bounds__(BS) k_refit_wide_level(uint32_t begin, uint32_t end, const float *__restrict__ aabb,
+                                                         const uint32_t *__restrict__ gid_of_pos, BvhFrame fr, uint4 *wnodes) {
+    const uint32_t slot = blockIdx.x * BS + threadIdx.x; // one thread per child slot
+    const uint32_t w = begin + slot / EGR_WIDTH, k = slot % EGR_WIDTH;
+    if (w >= end) return;
+    const uint32_t link = wnodes[(size_t)w * EGR_WIDTH + k].w;
+    uint32_t lo[3] = {65535u, 65535u, 65535u}, hi[3] = {0u, 0u, 0u};
+    if (link == EGR_EMPTY_SLOT) {
+    } else if (link & EGR_LEAF_FLAG) {
+        const uint32_t gid = gid_of_pos[link & ~EGR_LEAF_FLAG];
+        const float *bx = aabb + 6 * (size_t)gid;
+        if (bx[0] <= bx[3]) {
+            const float fo[3] = {fr.ox, fr.oy, fr.oz}, fs[3] = {fr.sx, fr.sy, fr.sz};
 #pragma unroll
-    for (int k = 0; k < EGR_CLUSTER; k++) {
-        const uint32_t pos = EGR_CLUSTER * j + k;
-        if (pos >= n) continue;
-        const uint32_t gid = gid_of_pos[pos];
+            for (int a = 0; a < 3; a++) lo[a] = quant_lo(bx[a], fo[a], fs[a]), hi[a] = quant_hi(bx[3 + a], fo[a], fs[a]);
+        }
+    } else {
+        const uint4 *ch = wnodes + (size_t)link * EGR_WIDTH;
 #pragma unroll
-        for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], aabb[6 * gid + a]), hi[a] = fmaxf(hi[a], aabb[6 * gid + 3 + a]);
+        for (int c = 0; c < EGR_WIDTH; c++) {
+            uint32_t l[3], h[3];
+            unpack_box(ch[c], l, h);
+#pragma unroll
+            for (int a = 0; a < 3; a++) lo[a] = min(lo[a], l[a]), hi[a] = max(hi[a], h[a]);
+        }
     }
-    const uint32_t p = leaf_pre[j];
-    const uint32_t link = EGR_LEAF_FLAG | j; // members = sorted positions [C*j, C*j+C)
-    const float fo[3] = {fr.ox, fr.oy, fr.oz}, fs[3] = {fr.sx, fr.sy, fr.sz};
-    uint32_t ql[3], qh[3];
-    const bool empty = !(lo[0] <= hi[0]);
-#pragma unroll
-    for (int a = 0; a < 3; a++) ql[a] = empty ? 65535u : quant_lo(lo[a], fo[a], fs[a]), qh[a] = empty ? 0u : quant_hi(hi[a], fo[a], fs[a]);
-    qnodes[p] = pack_box(ql, qh, link);
-}
-// One depth level: box(p) = box(left = p+1) U box(right). right = skip(left) for an internal left child, left+1 for a
-// leaf. Children are one level deeper and were written by an earlier launch.
-__device__ __forceinline__ void refit_one(uint32_t p, uint4 *nodes) {
-    const uint32_t l = p + 1;
-    const uint4 ln = nodes[l];
-    const uint32_t r = (ln.w & EGR_LEAF_FLAG) ? l + 1 : ln.w;
-    const uint4 rn = nodes[r];
-    nodes[p] = union_box(ln, rn, nodes[p].w);
-}
-__global__ void __launch_bounds__(BS) k_refit_level(uint32_t count, const uint32_t *__restrict__ order, uint4 *__restrict__ nodes) {
-    uint32_t i = blockIdx.x * BS + threadIdx.x;
-    if (i >= count) return;
-    refit_one(order[i], nodes);
-}
-// The shallow levels hold few nodes each; refit all of them in one single-workgroup launch instead of one
-// launch per level (levels processed deepest first, separated by workgroup barriers; same CU -> same L1/L2).
-__global__ void __launch_bounds__(1024) k_refit_top(int top_levels, const uint32_t *__restrict__ level_start,
-                                                    const uint32_t *__restrict__ order, uint4 *nodes) {
-    for (int d = top_levels - 1; d >= 0; d--) {
-        uint32_t b = level_start[d], e = level_start[d + 1];
-        for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) refit_one(order[i], nodes);
-        __threadfence_block();
-        __syncthreads();
-    }
+    wnodes[(size_t)w * EGR_WIDTH + k] = pack_box(lo, hi, link);
 }
 
 template <class T> void dfree(T *&p) {
@@ -320,32 +307,27 @@ template <class T> void dalloc(T *&p, size_t count) {
 } // namespace
 
 void egr_bvh_free(egr_context *c) {
-    dfree(c->qnodes), dfree(c->pos_of_gid), dfree(c->inst_w), dfree(c->inst_m), dfree(c->app), dfree(c->aabb), dfree(c->leaf_pre);
-    dfree(c->depth_order), dfree(c->sort_tmp), dfree(c->keys_in), dfree(c->keys_out), dfree(c->vals_in);
-    dfree(c->vals_out), dfree(c->k_left), dfree(c->k_right), dfree(c->k_parent), dfree(c->k_first), dfree(c->k_last);
-    dfree(c->node_depth), dfree(c->scratch_u32);
+    dfree(c->wnodes), dfree(c->pos_of_gid), dfree(c->inst_w), dfree(c->inst_m), dfree(c->app), dfree(c->aabb);
+    dfree(c->sort_tmp), dfree(c->keys_in), dfree(c->keys_out), dfree(c->vals_in), dfree(c->vals_out);
+    dfree(c->k_left), dfree(c->k_right), dfree(c->k_parent), dfree(c->k_first), dfree(c->k_last), dfree(c->wide_of), dfree(c->scratch_u32);
     c->n_alloc = 0;
     c->n_built = 0;
     c->bvh_valid = false;
 }
 
 void egr_bvh_reserve(egr_context *c, uint32_t n) {
-    if (n <= c->n_alloc && c->qnodes) return;
+    if (n <= c->n_alloc && c->wnodes) return;
     uint32_t cap = std::max<uint32_t>(n + n / 8, 256); // head-room: the reference grows by +75k far-field points
-    uint32_t ccap = cap / EGR_CLUSTER + 64;             // clusters
-    dalloc(c->qnodes, 2 * (size_t)ccap + 16);
+    dalloc(c->wnodes, (size_t)cap * EGR_WIDTH + 64);   // <= n-1 wide nodes (one per binary internal node, usually ~n/5)
     dalloc(c->pos_of_gid, cap);
     dalloc(c->inst_w, 3 * (size_t)cap);
     dalloc(c->inst_m, 3 * (size_t)cap);
     dalloc(c->app, 3 * (size_t)cap);
     dalloc(c->aabb, 6 * (size_t)cap);
-    dalloc(c->leaf_pre, ccap);
-    dalloc(c->depth_order, ccap);
     dalloc(c->keys_in, cap), dalloc(c->keys_out, cap), dalloc(c->vals_in, cap), dalloc(c->vals_out, cap);
-    dalloc(c->k_left, ccap), dalloc(c->k_right, ccap), dalloc(c->k_parent, 2 * (size_t)ccap);
-    dalloc(c->k_first, ccap), dalloc(c->k_last, ccap);
-    dalloc(c->node_depth, 2 * (size_t)ccap);
-    if (!c->scratch_u32) dalloc(c->scratch_u32, 16 + 2 * EGR_MAX_DEPTH_BINS + 8);
+    dalloc(c->k_left, cap), dalloc(c->k_right, cap), dalloc(c->k_parent, 2 * (size_t)cap);
+    dalloc(c->k_first, cap), dalloc(c->k_last, cap), dalloc(c->wide_of, cap);
+    if (!c->scratch_u32) dalloc(c->scratch_u32, 64);
     size_t bytes = 0;
     EGR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)cap, 0, 63, 0));
     dfree(c->sort_tmp);
@@ -356,36 +338,29 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
 }
 
 static void refit_boxes(egr_context *c, hipStream_t s) {
-    const uint32_t nc = c->n_clusters;
-    hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(nc)), dim3(BS), 0, s, c->n_built, nc, c->aabb, c->vals_out, c->leaf_pre, c->frame, c->qnodes);
-    // depth_start[d]..depth_start[d+1] = internal nodes at depth d. Deep levels: one launch each.
-    // Shallow levels (cumulatively <= 8192 nodes): one single-workgroup launch.
-    int top = 0;
-    while (top <= (int)c->max_depth && c->depth_start[top + 1] <= 8192u) top++;
-    for (int d = (int)c->max_depth; d >= top; d--) {
-        uint32_t b = c->depth_start[d], e = c->depth_start[d + 1];
-        if (e > b) hipLaunchKernelGGL(k_refit_level, dim3(nblk(e - b)), dim3(BS), 0, s, e - b, c->depth_order + b, c->qnodes);
+    // level_start[L]..level_start[L+1] = wide nodes of level L (root = level 0). Deepest level first.
+    for (int L = (int)c->level_start.size() - 2; L >= 0; L--) {
+        const uint32_t b = c->level_start[L], e = c->level_start[L + 1];
+        if (e > b)
+            hipLaunchKernelGGL(k_refit_wide_level, dim3(nblk((uint64_t)(e - b) * EGR_WIDTH)), dim3(BS), 0, s, b, e, c->aabb, c->vals_out, c->frame,
+                               c->wnodes);
     }
-    if (top > 0 && c->depth_start[top] > 0)
-        hipLaunchKernelGGL(k_refit_top, dim3(1), dim3(1024), 0, s, top, c->scratch_u32 + 16 + EGR_MAX_DEPTH_BINS, c->depth_order,
-                           c->qnodes);
 }
 
 void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     const uint32_t n = c->g.count;
     egr_bvh_reserve(c, n);
     c->n_built = n;
-    c->n_clusters = (n + EGR_CLUSTER - 1) / EGR_CLUSTER;
+    c->num_wide = 0;
     c->max_depth = 0;
-    c->depth_start.assign(EGR_MAX_DEPTH_BINS + 1, 0);
+    c->level_start.assign(1, 0);
     c->frame = BvhFrame{0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
     if (n == 0) {
         c->bvh_valid = true;
         return;
     }
-    const uint32_t nc = c->n_clusters;
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb); // boxes for frame + leaves
-    uint32_t *bounds = c->scratch_u32, *hist = c->scratch_u32 + 16, *cursor = c->scratch_u32 + 16 + EGR_MAX_DEPTH_BINS;
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb); // boxes for the frame
+    uint32_t *bounds = c->scratch_u32, *counters = c->scratch_u32 + 16;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, bounds);
     hipLaunchKernelGGL(k_bounds, dim3(nblk(n)), dim3(BS), 0, s, n, c->aabb, bounds);
     uint32_t hb[6];
@@ -406,32 +381,43 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(BS), 0, s, n, c->g.mean, c->frame, c->keys_in, c->vals_in);
     size_t bytes = c->sort_tmp_bytes;
     EGR_HIP(rocprim::radix_sort_pairs(c->sort_tmp, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)n, 0, 63, s));
-    uint64_t *ckeys = c->keys_in; // free after the sort
-    hipLaunchKernelGGL(k_clusters, dim3(nblk(nc)), dim3(BS), 0, s, n, nc, c->keys_out, ckeys);
     hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(n)), dim3(BS), 0, s, n, c->vals_out, c->pos_of_gid);
     hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb); // records in leaf order
-    if (nc >= 2)
-        hipLaunchKernelGGL(k_karras, dim3(nblk(nc - 1)), dim3(BS), 0, s, (int)nc, ckeys, c->k_left, c->k_right, c->k_parent, c->k_first,
+    if (n == 1) { // a single leaf under a one-child root
+        uint4 root[EGR_WIDTH];
+        for (int k = 0; k < EGR_WIDTH; k++) root[k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, k == 0 ? (EGR_LEAF_FLAG | 0u) : EGR_EMPTY_SLOT);
+        EGR_HIP(hipMemcpyAsync(c->wnodes, root, sizeof(root), hipMemcpyHostToDevice, s));
+        EGR_HIP(hipStreamSynchronize(s));
+        c->num_wide = 1;
+        c->level_start = {0, 1};
+    } else {
+        hipLaunchKernelGGL(k_karras, dim3(nblk(n - 1)), dim3(BS), 0, s, (int)n, c->keys_out, c->k_left, c->k_right, c->k_parent, c->k_first,
                            c->k_last);
-    EGR_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 2 * EGR_MAX_DEPTH_BINS + 32, s));
-    hipLaunchKernelGGL(k_preorder, dim3(nblk(2 * (uint64_t)nc - 1)), dim3(BS), 0, s, (int)nc, c->k_left, c->k_parent, c->k_first,
-                       c->k_last, c->qnodes, c->leaf_pre, c->node_depth, hist);
-    std::vector<uint32_t> h(EGR_MAX_DEPTH_BINS);
-    EGR_HIP(hipMemcpyAsync(h.data(), hist, sizeof(uint32_t) * EGR_MAX_DEPTH_BINS, hipMemcpyDeviceToHost, s));
-    EGR_HIP(hipStreamSynchronize(s));
-    if (h[EGR_MAX_DEPTH_BINS - 1] != 0) throw EgrCheck{hipErrorInvalidValue, "LBVH deeper than EGR_MAX_DEPTH_BINS"};
-    uint32_t maxd = 0;
-    for (int d = 0; d < EGR_MAX_DEPTH_BINS; d++) {
-        c->depth_start[d + 1] = c->depth_start[d] + h[d];
-        if (h[d]) maxd = d;
+        // level-by-level collapse; frontiers ping-pong in keys_in (free after the sort)
+        uint32_t *fr0 = reinterpret_cast<uint32_t *>(c->keys_in), *fr1 = fr0 + c->n_alloc;
+        uint32_t init[4] = {1u, 0u, 0u, 0u}; // wide node 0 = binary root
+        uint32_t zero = 0;
+        EGR_HIP(hipMemcpyAsync(counters, init, sizeof(init), hipMemcpyHostToDevice, s));
+        EGR_HIP(hipMemcpyAsync(fr0, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, s));     // frontier = {binary root}
+        EGR_HIP(hipMemcpyAsync(c->wide_of, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, s)); // wide_of[root] = 0
+        uint32_t count = 1, nw = 1;
+        c->level_start = {0, 1};
+        while (count > 0) {
+            hipLaunchKernelGGL(k_collapse_level, dim3(nblk(count)), dim3(BS), 0, s, (int)n, count, fr0, c->k_left, c->k_right, c->k_first, c->k_last,
+                               c->wide_of, counters, fr1, c->wnodes);
+            uint32_t hc[2];
+            EGR_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
+            EGR_HIP(hipStreamSynchronize(s));
+            count = hc[1];
+            if (hc[0] > nw) c->level_start.push_back(hc[0]);
+            nw = hc[0];
+            EGR_HIP(hipMemcpyAsync(counters + 1, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            std::swap(fr0, fr1);
+            if (c->level_start.size() > 200) throw EgrCheck{hipErrorInvalidValue, "wide BVH deeper than 200 levels"};
+        }
+        c->num_wide = nw;
     }
-    c->max_depth = maxd;
-    // cursors double as the device copy of level_start for k_refit_top (it reads entries [0, top])
-    EGR_HIP(hipMemcpyAsync(cursor, c->depth_start.data(), sizeof(uint32_t) * EGR_MAX_DEPTH_BINS, hipMemcpyHostToDevice, s));
-    // scatter needs its own running cursors: a second copy placed in vals_in (free after the sort)
-    uint32_t *run = c->vals_in;
-    EGR_HIP(hipMemcpyAsync(run, c->depth_start.data(), sizeof(uint32_t) * EGR_MAX_DEPTH_BINS, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_scatter_depth, dim3(nblk(2 * (uint64_t)nc - 1)), dim3(BS), 0, s, 2 * nc - 1, c->node_depth, run, c->depth_order);
+    c->max_depth = (uint32_t)c->level_start.size() - 1;
     refit_boxes(c, s);
     EGR_HIP(hipStreamSynchronize(s));
     c->bvh_valid = true;
@@ -445,17 +431,17 @@ void egr_bvh_refit(egr_context *c, hipStream_t s) {
     refit_boxes(c, s);
 }
 
-// Host-side structural self check (debug / tests): pre-order links, exact integer unions, every leaf box contains
-// its members' boxes (after decoding), every gaussian is a member of exactly one reachable cluster.
+// Host-side structural self check (debug / tests): every child index valid and visited once, internal slot boxes are
+// the exact integer union of the child's slots, every leaf slot box contains its gaussian's box (after decoding),
+// every gaussian is reachable exactly once.
 int egr_bvh_check(egr_context *c, hipStream_t s, std::string &msg) {
-    const uint32_t n = c->n_built, nc = c->n_clusters;
+    const uint32_t n = c->n_built, nw = c->num_wide;
     if (n == 0) return 0;
-    const uint32_t nn = 2 * nc - 1;
-    std::vector<uint4> nodes(nn);
+    std::vector<uint4> nodes((size_t)nw * EGR_WIDTH);
     std::vector<uint32_t> gop(n);
     std::vector<float> aabb(6 * (size_t)n);
     EGR_HIP(hipStreamSynchronize(s));
-    EGR_HIP(hipMemcpy(nodes.data(), c->qnodes, sizeof(uint4) * nn, hipMemcpyDeviceToHost));
+    EGR_HIP(hipMemcpy(nodes.data(), c->wnodes, sizeof(uint4) * nodes.size(), hipMemcpyDeviceToHost));
     EGR_HIP(hipMemcpy(gop.data(), c->vals_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     EGR_HIP(hipMemcpy(aabb.data(), c->aabb, sizeof(float) * aabb.size(), hipMemcpyDeviceToHost));
     const BvhFrame fr = c->frame;
@@ -468,53 +454,51 @@ int egr_bvh_check(egr_context *c, hipStream_t s, std::string &msg) {
         if (!is_lo && q == 65535) return 1e300;
         return (double)fo[a] + ((double)q - 2.0) / (double)fs[a];
     };
-    std::vector<uint8_t> seen(n, 0), cseen(nc, 0);
+    std::vector<uint8_t> seen(n, 0), wseen(nw, 0);
     char buf[256];
-    std::vector<std::pair<uint32_t, uint32_t>> st;
-    st.push_back({0, nn});
+    std::vector<uint32_t> st;
+    st.push_back(0);
+    wseen[0] = 1;
     while (!st.empty()) {
-        auto [p, end] = st.back();
+        const uint32_t w = st.back();
         st.pop_back();
-        const uint4 q = nodes[p];
-        uint32_t lo[3], hi[3];
-        unpack(q, lo, hi);
-        if (q.w & EGR_LEAF_FLAG) {
-            const uint32_t j = q.w & ~EGR_LEAF_FLAG;
-            if (end != p + 1) { snprintf(buf, sizeof buf, "leaf %u does not end its subtree (%u)", p, end); msg = buf; return 3; }
-            if (j >= nc || cseen[j]) { snprintf(buf, sizeof buf, "leaf %u: bad/duplicate cluster %u", p, j); msg = buf; return 2; }
-            cseen[j] = 1;
-            uint32_t id[EGR_CLUSTER];
-            for (int k = 0; k < EGR_CLUSTER; k++) id[k] = (EGR_CLUSTER * j + k < n) ? gop[EGR_CLUSTER * j + k] : 0xFFFFFFFFu;
-            for (int k = 0; k < EGR_CLUSTER; k++) {
-                if (id[k] == 0xFFFFFFFFu) continue;
-                if (id[k] >= n || seen[id[k]]) { snprintf(buf, sizeof buf, "cluster %u: bad/duplicate member %u", j, id[k]); msg = buf; return 9; }
-                seen[id[k]] = 1;
-                const float *b = &aabb[6 * (size_t)id[k]];
-                if (!(b[0] <= b[3])) continue; // unusable member has an empty box
+        bool gap = false;
+        for (int k = 0; k < EGR_WIDTH; k++) {
+            const uint4 q = nodes[(size_t)w * EGR_WIDTH + k];
+            uint32_t lo[3], hi[3];
+            unpack(q, lo, hi);
+            if (q.w == EGR_EMPTY_SLOT) { gap = true; continue; }
+            if (gap) { snprintf(buf, sizeof buf, "node %u: slot %d used after an empty slot", w, k); msg = buf; return 10; }
+            if (q.w & EGR_LEAF_FLAG) {
+                const uint32_t pos = q.w & ~EGR_LEAF_FLAG;
+                if (pos >= n || seen[gop[pos]]) { snprintf(buf, sizeof buf, "node %u slot %d: bad/duplicate leaf %u", w, k, pos); msg = buf; return 2; }
+                const uint32_t gid = gop[pos];
+                seen[gid] = 1;
+                const float *b = &aabb[6 * (size_t)gid];
+                if (!(b[0] <= b[3])) continue; // unusable gaussian: empty box
                 for (int a = 0; a < 3; a++)
                     if (dec(lo[a], a, true) > (double)b[a] || dec(hi[a], a, false) < (double)b[3 + a]) {
-                        snprintf(buf, sizeof buf, "leaf %u (cluster %u) box does not contain member %u on axis %d", p, j, id[k], a); msg = buf; return 4;
+                        snprintf(buf, sizeof buf, "node %u slot %d: box does not contain gaussian %u on axis %d", w, k, gid, a); msg = buf; return 4;
                     }
+                continue;
             }
-            continue;
+            const uint32_t ch = q.w;
+            if (ch >= nw || wseen[ch]) { snprintf(buf, sizeof buf, "node %u slot %d: bad/duplicate child %u", w, k, ch); msg = buf; return 6; }
+            wseen[ch] = 1;
+            uint32_t ulo[3] = {65535u, 65535u, 65535u}, uhi[3] = {0u, 0u, 0u};
+            for (int cc = 0; cc < EGR_WIDTH; cc++) {
+                uint32_t l[3], h[3];
+                unpack(nodes[(size_t)ch * EGR_WIDTH + cc], l, h);
+                for (int a = 0; a < 3; a++) ulo[a] = std::min(ulo[a], l[a]), uhi[a] = std::max(uhi[a], h[a]);
+            }
+            for (int a = 0; a < 3; a++)
+                if (lo[a] != ulo[a] || hi[a] != uhi[a]) { snprintf(buf, sizeof buf, "node %u slot %d: box is not the union of child %u", w, k, ch); msg = buf; return 7; }
+            st.push_back(ch);
         }
-        if (q.w != end) { snprintf(buf, sizeof buf, "node %u: skip %u != subtree end %u", p, q.w, end); msg = buf; return 1; }
-        const uint32_t l = p + 1;
-        if (l >= nn) { msg = "internal node without child"; return 5; }
-        const uint4 ln = nodes[l];
-        const uint32_t r = (ln.w & EGR_LEAF_FLAG) ? l + 1 : ln.w;
-        if (r <= l || r >= end) { snprintf(buf, sizeof buf, "node %u: right child %u outside (%u,%u)", p, r, l, end); msg = buf; return 6; }
-        const uint4 rn = nodes[r];
-        uint32_t llo[3], lhi[3], rlo[3], rhi[3];
-        unpack(ln, llo, lhi), unpack(rn, rlo, rhi);
-        for (int a = 0; a < 3; a++)
-            if (lo[a] != std::min(llo[a], rlo[a]) || hi[a] != std::max(lhi[a], rhi[a])) {
-                snprintf(buf, sizeof buf, "node %u: box is not the union of children %u,%u", p, l, r); msg = buf; return 7;
-            }
-        st.push_back({l, r});
-        st.push_back({r, end});
     }
     for (uint32_t i = 0; i < n; i++)
         if (!seen[i]) { snprintf(buf, sizeof buf, "gaussian %u unreachable", i); msg = buf; return 8; }
+    for (uint32_t w = 0; w < nw; w++)
+        if (!wseen[w]) { snprintf(buf, sizeof buf, "wide node %u unreachable", w); msg = buf; return 9; }
     return 0;
 }

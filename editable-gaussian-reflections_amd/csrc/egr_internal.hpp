@@ -13,10 +13,11 @@
 #define EGR_TILE 8            // one wave = one 8x8 pixel tile
 #define EGR_MACRO_TILE 16     // multi-GPU partition granule (2x2 wave tiles)
 #define EGR_INTERNAL_NODE 0xFFFFFFFFu
-#define EGR_LEAF_FLAG 0x80000000u  // qnode.w: leaf -> EGR_LEAF_FLAG | cluster id, internal -> skip index
-#ifndef EGR_CLUSTER
-#define EGR_CLUSTER 1              // gaussians per leaf cluster (1, 2 or 4; measured: 4 costs more false-positive cube tests than it saves nodes)
-#endif
+#define EGR_LEAF_FLAG 0x80000000u  // child slot link: leaf -> EGR_LEAF_FLAG | record index, internal -> child node index
+#define EGR_EMPTY_SLOT 0xFFFFFFFFu // unused child slot (checked before the leaf flag)
+#define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
+#define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
+#define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
 #define EGR_HIT_BLOCK_ROWS 8  // composited-hit arena block: 8 rows x 64 lanes x 16 B (+1 header row)
 #define EGR_MAX_DEPTH_BINS 256
 
@@ -33,7 +34,7 @@ inline void egr_hip_check(hipError_t e, const char *what) {
 // inst_w : float4[3N]   rows of W = M^-1 (world->object), snapshot at update/rebuild      48 B
 // inst_m : float4[3N]   rows of M   (object->world),      snapshot at update/rebuild      48 B
 // app    : float4[3N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y) (f0.z, rough, opacity, sigma) 48 B
-// qnodes : uint4[2*Nc-1]  threaded pre-order LBVH over Nc = ceil(N/4) leaf clusters, 16 B / node:
+// wnodes : uint4[8*Nw]     8-wide BVH, one 128-B line per node; child slot (16 B):
 //          x = lo.x | lo.y<<16, y = lo.z | hi.x<<16, z = hi.y | hi.z<<16 (16-bit cells of the build frame), w = link
 // inst_w / inst_m / app are indexed by SORTED POSITION (Morton / leaf order), cluster j = positions [C*j, C*j+C);
 // gid_of_pos / pos_of_gid map between sorted positions and the caller's gaussian ids
@@ -46,7 +47,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     int width, height, tiles_x, tiles_y;
     uint32_t num_pixels;
     uint32_t n;          // gaussians
-    uint32_t num_nodes;  // 2*clusters-1 (0 if n == 0)
+    uint32_t num_nodes;  // wide nodes (0 if n == 0)
     // partition
     int rank, world;
     uint32_t num_tasks;  // wave tiles owned by this rank
@@ -57,7 +58,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     egr_framebuffer fb;
     egr_metadata meta;
     egr_stats stats;
-    const uint4 *qnodes;
+    const uint4 *wnodes;
     const uint32_t *gid_of_pos; // [n] gaussian id stored at sorted position p
     const uint32_t *pos_of_gid; // [n] inverse
     BvhFrame frame;
@@ -67,7 +68,8 @@ struct DeviceView { // everything a kernel needs, passed by value
     // per-launch scratch
     float *cand_keys;      // [slots][cand_cap][64]
     float2 *cand_vals;     // [slots][cand_cap][64]  (alpha, gaussian id bits)
-    uint32_t *cand_queue;  // [slots][cand_cap][64]  leaf-cluster ids awaiting evaluation (per-lane walk)
+    uint32_t *cand_queue;  // [slots][cand_cap][64]  leaf record indices awaiting evaluation (per-lane walk)
+    uint32_t *stack_spill; // [slots][EGR_GSTK][64] traversal stack entries beyond the LDS part
     uint32_t cand_cap;
     uint32_t num_slots;    // resident waves
     float4 *hit_arena;     // blocks of (1 + EGR_HIT_BLOCK_ROWS) rows x 64 lanes
@@ -117,15 +119,14 @@ struct egr_context {
     // BVH
     uint32_t n_alloc = 0;      // capacity of per-gaussian buffers
     uint32_t n_built = 0;      // n the tree topology was built for
-    uint4 *qnodes = nullptr;
+    uint4 *wnodes = nullptr;
+    uint32_t num_wide = 0;
+    uint32_t *wide_of = nullptr;          // build temporary: binary internal id -> wide node index
+    std::vector<uint32_t> level_start;    // host: wide-node index range of each level of the wide tree
     uint32_t *pos_of_gid = nullptr; // gid_of_pos is vals_out (kept after the build)
-    uint32_t n_clusters = 0;
     BvhFrame frame{0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
     float4 *inst_w = nullptr, *inst_m = nullptr, *app = nullptr;
     float *aabb = nullptr;             // [n][6] instance boxes (lo, hi)
-    uint32_t *leaf_pre = nullptr;      // [clusters] pre-order index of each cluster's leaf
-    uint32_t *depth_order = nullptr;   // [n-1] internal nodes (pre-order idx) grouped by depth
-    std::vector<uint32_t> depth_start; // host: bucket offsets, size max_depth+2
     uint32_t max_depth = 0;
     // build temporaries
     void *sort_tmp = nullptr;
@@ -134,12 +135,11 @@ struct egr_context {
     uint32_t *vals_in = nullptr, *vals_out = nullptr;
     int32_t *k_left = nullptr, *k_right = nullptr, *k_parent = nullptr; // Karras arrays (index space: internal i, leaf n-1+j)
     uint32_t *k_first = nullptr, *k_last = nullptr;
-    uint32_t *node_depth = nullptr;
     uint32_t *scratch_u32 = nullptr; // bounds (6), depth histogram, cursors
     // launch scratch
     float *cand_keys = nullptr;
     float2 *cand_vals = nullptr;
-    uint32_t *cand_queue = nullptr;
+    uint32_t *cand_queue = nullptr, *stack_spill = nullptr;
     uint32_t cand_cap = 0, num_slots = 0;
     float4 *hit_arena = nullptr;
     uint32_t hit_blocks_cap = 0;

@@ -131,15 +131,17 @@ EGR_DI uint4 load_u4_uniform(const uint4 *base, uint32_t idx) { // idx must be w
     return base[idx];
 #endif
 }
-// Segment [tmin,tmax] vs a quantised node box, in the frame's cell coordinates (oq, invq = 1/(d*scale)).
-// Cell 0 / 65535 are the out-of-frame sentinels: -inf / +inf.
-EGR_DI bool qslab_hit(uint4 q, f3 oq, f3 invq, float tmin, float tmax) {
+// Segment [tmin,tmax] vs a quantised child box in the frame's cell coordinates: plane distance = fma(cell, invq, ncq)
+// with invq = 1/(d*scale), ncq = -origin_cell*invq. Cells 0 / 65535 are the out-of-frame sentinels (-inf / +inf).
+// The fused form moves a plane by < 0.01 cell (boxes carry a full extra cell each side); for an exactly axis-parallel
+// ray both products are inf and the axis drops out (conservative).
+EGR_DI bool qslab_hit(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
     const uint32_t lx = q.x & 0xFFFFu, ly = q.x >> 16, lz = q.y & 0xFFFFu, hx = q.y >> 16, hy = q.z & 0xFFFFu, hz = q.z >> 16;
     const float flx = lx == 0u ? -3.0e38f : (float)lx, fly = ly == 0u ? -3.0e38f : (float)ly, flz = lz == 0u ? -3.0e38f : (float)lz;
     const float fhx = hx == 65535u ? 3.0e38f : (float)hx, fhy = hy == 65535u ? 3.0e38f : (float)hy, fhz = hz == 65535u ? 3.0e38f : (float)hz;
-    const float ax = (flx - oq.x) * invq.x, bx = (fhx - oq.x) * invq.x;
-    const float ay = (fly - oq.y) * invq.y, by = (fhy - oq.y) * invq.y;
-    const float az = (flz - oq.z) * invq.z, bz = (fhz - oq.z) * invq.z;
+    const float ax = fmaf(flx, invq.x, ncq.x), bx = fmaf(fhx, invq.x, ncq.x);
+    const float ay = fmaf(fly, invq.y, ncq.y), by = fmaf(fhy, invq.y, ncq.y);
+    const float az = fmaf(flz, invq.z, ncq.z), bz = fmaf(fhz, invq.z, ncq.z);
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return t0 <= t1;
@@ -206,7 +208,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     const int lane = threadIdx.x;
     float *__restrict__ keys = v.cand_keys + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
     float2 *__restrict__ vals = v.cand_vals + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
-    const uint4 *__restrict__ qnodes = v.qnodes;
+    const uint4 *__restrict__ wnodes = v.wnodes;
+    __shared__ uint32_t lstk[EGR_LSTK][EGR_WAVE]; // per-lane traversal stack (this workgroup is one wave)
     const float4 *__restrict__ app = v.app;
     const uint32_t END = v.num_nodes;
 
@@ -259,10 +262,12 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         // box the segment overlaps; phase B evaluates the queue. The queue lives in the lane's key column
         // (ids are overwritten by keys, write index <= read index).
         const bool ray_ok = active && finite3(ro) && finite3(rd); // NaN rays (ggx_brdf.h:163) hit nothing
-        // the ray in the quantisation frame of the tree: cell = (x - o) * s + 2, same t parametrisation
-        const f3 oq = mk3((ro.x - v.frame.ox) * v.frame.sx + 2.0f, (ro.y - v.frame.oy) * v.frame.sy + 2.0f, (ro.z - v.frame.oz) * v.frame.sz + 2.0f);
+        // the ray in the quantisation frame of the tree: cell = (x - o) * s + 2, same t parametrisation.
+        // slab plane distance t = (cell - oq) / (d * s) is evaluated as fma(cell, invq, -oq * invq).
         const f3 invq = mk3(1.0f / (rd.x * v.frame.sx), 1.0f / (rd.y * v.frame.sy), 1.0f / (rd.z * v.frame.sz));
-        uint32_t nq = 0;      // leaf clusters queued for evaluation (per-lane walk)
+        const f3 ncq = mk3(-((ro.x - v.frame.ox) * v.frame.sx + 2.0f) * invq.x, -((ro.y - v.frame.oy) * v.frame.sy + 2.0f) * invq.y,
+                           -((ro.z - v.frame.oz) * v.frame.sz + 2.0f) * invq.z);
+        uint32_t nq = 0;      // leaves queued for evaluation (per-lane walk)
         uint32_t cnt = 0, traversed = 0;
         float full_T = 1.0f;
         bool overflow = false;
@@ -323,75 +328,92 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             packet = __builtin_amdgcn_readfirstlane(packet ? 1 : 0) != 0;
         }
         if (packet) {
-            uint32_t unode = 0u; // wave-uniform cursor
-            while (unode < END) {
-                const uint32_t un = (uint32_t)__builtin_amdgcn_readfirstlane((int)unode);
-                const uint4 qn = load_u4_uniform(qnodes, un);
-                const bool hit = ray_ok && qslab_hit(qn, oq, invq, near_plane, far_plane);
-                const bool any = __ballot(hit) != 0ull;
-                const bool leaf = (qn.w & EGR_LEAF_FLAG) != 0u;
+            // ---- packet walk: wave-uniform DFS over the 8-wide tree; stack in LDS (uniform address), node slots, leaf
+            // transforms and live records through the scalar cache; each lane tests its own ray, a child is entered /
+            // evaluated when ANY lane overlaps its box.
+            uint32_t *ustk = &lstk[0][0];
+            uint32_t usp = 0;
+            if (__ballot(ray_ok) != 0ull) {
+                if (lane == 0) ustk[0] = 0u;
+                usp = 1;
+            }
+            while (usp > 0) {
+                usp--;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ustk[usp]);
 #ifdef EGR_TRAVERSAL_STATS
-                st_visits += hit ? 1u : 0u;
                 st_inner += (lane == 0);
-                st_leafhits += (hit && leaf) ? 1u : 0u;
-                st_outer += (lane == 0 && any && leaf);
 #endif
-                if (any && leaf) {
-                    const uint32_t first = EGR_CLUSTER * (qn.w & ~EGR_LEAF_FLAG); // members = sorted positions, contiguous records
 #pragma unroll
-                    for (int k = 0; k < EGR_CLUSTER; k++) {
-                        const uint32_t p = first + k;
-                        if (p >= v.n) continue; // uniform
+                for (int k = 0; k < EGR_WIDTH; k++) {
+                    const uint4 sl = load_u4_uniform(wnodes, w * EGR_WIDTH + (uint32_t)k);
+                    if (sl.w == EGR_EMPTY_SLOT) break; // uniform: slots are packed from 0
+                    const bool hit = ray_ok && qslab_hit(sl, invq, ncq, near_plane, far_plane);
+                    if (__ballot(hit) == 0ull) continue;
+#ifdef EGR_TRAVERSAL_STATS
+                    st_visits += hit ? 1u : 0u;
+#endif
+                    if (sl.w & EGR_LEAF_FLAG) {
+                        const uint32_t p = sl.w & ~EGR_LEAF_FLAG;
+#ifdef EGR_TRAVERSAL_STATS
+                        st_leafhits += hit ? 1u : 0u;
+                        st_outer += (lane == 0);
+#endif
                         const float4 w0 = load_f4_uniform(v.inst_w, 3 * p), w1 = load_f4_uniform(v.inst_w, 3 * p + 1), w2 = load_f4_uniform(v.inst_w, 3 * p + 2);
                         const float4 a2 = load_f4_uniform(app, 3 * p + 2);
                         if (hit) evaluate(p, w0, w1, w2, a2);
+                    } else {
+                        if (lane == 0) ustk[usp] = sl.w;
+                        usp++;
                     }
                 }
-                unode = (any && !leaf) ? un + 1 : (leaf ? un + 1 : qn.w);
             }
         } else {
+            // ---- per-lane walk: DFS with a per-lane stack (LDS [depth][lane], conflict-free; deeper entries spill to a
+            // per-wave global column). Phase A queues the leaves whose box the lane's segment overlaps, phase B evaluates
+            // them (decoupled so that the wave does not rendezvous at every leaf).
             uint32_t *__restrict__ queue = v.cand_queue + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
-            const bool grp_ok = v.group_lanes <= 1u ? ray_ok : (((__ballot(ray_ok) >> ((uint32_t)lane & ~(v.group_lanes - 1u))) & (v.group_lanes >= 64u ? ~0ull : ((1ull << v.group_lanes) - 1ull))) != 0ull);
-            uint32_t node = grp_ok ? 0u : END;
+            uint32_t *__restrict__ gstk = v.stack_spill + (size_t)blockIdx.x * EGR_GSTK * EGR_WAVE;
+            uint32_t sp = 0;
+            auto push = [&](uint32_t x) {
+                if (sp < EGR_LSTK) lstk[sp][lane] = x, sp++;
+                else if (sp < EGR_LSTK + EGR_GSTK) gstk[(size_t)(sp - EGR_LSTK) * EGR_WAVE + lane] = x, sp++;
+                else overflow = true; // > 256 pending subtrees: cannot happen for trees the builder produces
+            };
+            if (ray_ok) push(0u);
             for (;;) {
-                // ---- phase A: queue the leaf clusters whose box the segment of ANY lane of this lane's group overlaps.
-                // Lanes are grouped in runs of G (= v.group_lanes: 1 = fully per-lane ... 64 = whole-wave packet); a group
-                // walks the tree in lockstep, so its G node fetches hit ONE cache line instead of G: the per-lane walk is
-                // bound by L1 line fills (every divergent 16-B gather pulls a 128-B line), not by instructions.
-                const uint32_t gsh = (uint32_t)lane & ~(v.group_lanes - 1u);
-                const unsigned long long gmask = v.group_lanes >= 64u ? ~0ull : ((1ull << v.group_lanes) - 1ull);
-                while (node < END && nq < v.cand_cap) {
-                    const uint4 qn = qnodes[node];
-                    const bool hit = ray_ok && qslab_hit(qn, oq, invq, near_plane, far_plane);
-                    const bool ghit = ((__ballot(hit) >> gsh) & gmask) != 0ull;
-                    const bool leaf = (qn.w & EGR_LEAF_FLAG) != 0u;
+                while (sp > 0 && nq + EGR_WIDTH <= v.cand_cap) { // phase A
+                    sp--;
+                    const uint32_t w = sp < EGR_LSTK ? lstk[sp][lane] : gstk[(size_t)(sp - EGR_LSTK) * EGR_WAVE + lane];
+                    const uint4 *__restrict__ nd = wnodes + (size_t)w * EGR_WIDTH;
+                    uint4 sl[EGR_WIDTH];
+#pragma unroll
+                    for (int k = 0; k < EGR_WIDTH; k++) sl[k] = nd[k]; // eight 16-B loads of ONE 128-B line
 #ifdef EGR_TRAVERSAL_STATS
                     st_visits++;
                     if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
 #endif
-                    if (ghit && leaf) queue[(size_t)nq * EGR_WAVE + lane] = qn.w & ~EGR_LEAF_FLAG, nq++;
-                    node = (leaf || ghit) ? node + 1 : qn.w;
+#pragma unroll
+                    for (int k = EGR_WIDTH - 1; k >= 0; k--) { // reverse: slot 0 is popped first
+                        if (sl[k].w == EGR_EMPTY_SLOT) continue;
+                        if (!qslab_hit(sl[k], invq, ncq, near_plane, far_plane)) continue;
+                        if (sl[k].w & EGR_LEAF_FLAG) queue[(size_t)nq * EGR_WAVE + lane] = sl[k].w & ~EGR_LEAF_FLAG, nq++;
+                        else push(sl[k].w);
+                    }
                 }
 #ifdef EGR_TRAVERSAL_STATS
                 st_leafhits += nq;
 #endif
-                // ---- phase B: evaluate the members of the queued clusters ----
-                for (uint32_t q = 0; q < nq; q++) {
-                    const uint32_t first = EGR_CLUSTER * queue[(size_t)q * EGR_WAVE + lane];
+                for (uint32_t q = 0; q < nq; q++) { // phase B
+                    const uint32_t p = queue[(size_t)q * EGR_WAVE + lane];
 #ifdef EGR_TRAVERSAL_STATS
                     st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
 #endif
-#pragma unroll
-                    for (int k = 0; k < EGR_CLUSTER; k++) {
-                        const uint32_t p = first + k;
-                        if (p >= v.n) continue;
-                        const float4 w0 = v.inst_w[3 * p], w1 = v.inst_w[3 * p + 1], w2 = v.inst_w[3 * p + 2];
-                        const float4 a2 = app[3 * p + 2];
-                        if (ray_ok) evaluate(p, w0, w1, w2, a2);
-                    }
+                    const float4 w0 = v.inst_w[3 * p], w1 = v.inst_w[3 * p + 1], w2 = v.inst_w[3 * p + 2];
+                    const float4 a2 = app[3 * p + 2];
+                    evaluate(p, w0, w1, w2, a2);
                 }
                 nq = 0;
-                if (__ballot(node < END) == 0ull) break;
+                if (__ballot(sp > 0) == 0ull) break;
             }
         }
 
@@ -833,7 +855,7 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
+    dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
     if (c->control_host) (void)hipHostFree(c->control_host);
     c->control_host = nullptr;
 }
@@ -857,6 +879,7 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->cand_keys, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
     EGR_HIP(hipMalloc((void **)&c->cand_vals, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
     EGR_HIP(hipMalloc((void **)&c->cand_queue, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->stack_spill, (size_t)c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
     double bwd_bytes = (double)c->bwd_capacity * 36.0;
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
@@ -878,12 +901,12 @@ DeviceView egr_make_view(const egr_context *c) {
     v.tiles_x = (c->width + EGR_TILE - 1) / EGR_TILE, v.tiles_y = (c->height + EGR_TILE - 1) / EGR_TILE;
     v.num_pixels = (uint32_t)c->width * (uint32_t)c->height;
     v.n = c->g.count;
-    v.num_nodes = c->n_built ? 2 * c->n_clusters - 1 : 0;
+    v.num_nodes = c->num_wide;
     v.rank = c->rank, v.world = c->world;
     v.num_tasks = egr_num_tasks_for_rank(c);
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
-    v.qnodes = c->qnodes, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
+    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
