@@ -177,9 +177,13 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
             for (int k = 0; k < 2; k++)
                 fprintf(stderr, "[egr stats %s] lane node visits %llu, lane leaf-box hits %llu, wave inner iterations %llu, wave outer rounds %llu\n", k ? "bounce" : "primary",
                         (unsigned long long)u64(CW_DBG + 8 * k), (unsigned long long)u64(CW_DBG + 8 * k + 2), (unsigned long long)u64(CW_DBG + 8 * k + 4), (unsigned long long)u64(CW_DBG + 8 * k + 6));
+            for (int k = 0; k < 3; k++)
+                fprintf(stderr, "[egr stats forward step %d] first wave exit -> last wave exit: %.3f ms\n", k,
+                        (double)(u64(CW_DBG3 + 4 * k + 2) - u64(CW_DBG3 + 4 * k)) / 100e6 * 1e3);
             for (int k = 0; k < 2; k++)
-                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime, 100MHz ticks) traversal %llu composite %llu\n", k ? "bounce" : "primary",
-                        (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2));
+                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | per-lane walk: phase A %llu phase B %llu\n", k ? "bounce" : "primary",
+                        (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2), (unsigned long long)u64(CW_DBG2 + 8 + 4 * k),
+                        (unsigned long long)u64(CW_DBG2 + 8 + 4 * k + 2));
         }
     });
 }
@@ -228,14 +232,14 @@ int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, voi
         EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
         size_t n = c->n_built;
         std::vector<uint32_t> pos(n);
-        std::vector<float> tmp(n * 12);
+        std::vector<float> tmp(n * 16);
         EGR_HIP(hipMemcpy(pos.data(), c->pos_of_gid, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        auto unpermute = [&](const float4 *src, float *dst) { // records live at sorted positions; report them per gaussian id
-            EGR_HIP(hipMemcpy(tmp.data(), src, n * 12 * sizeof(float), hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < n; i++) memcpy(dst + 12 * i, tmp.data() + 12 * (size_t)pos[i], 12 * sizeof(float));
+        auto unpermute = [&](const float4 *src, float *dst, size_t stride) { // records live at sorted positions; report them per gaussian id
+            EGR_HIP(hipMemcpy(tmp.data(), src, n * stride * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; i++) memcpy(dst + 12 * i, tmp.data() + stride * (size_t)pos[i], 12 * sizeof(float));
         };
-        if (M) unpermute(c->inst_m, M);
-        if (W) unpermute(c->inst_w, W);
+        if (M) unpermute(c->inst_m, M, 12);
+        if (W) unpermute(c->inst_w, W, 16);
         if (aabb) EGR_HIP(hipMemcpy(aabb, c->aabb, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
     });
 }

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         // unusable: object-space origin (2,2,2), zero direction -> outside the unit cube for every ray
-        inst_w[3 * slot + a] = usable ? Wr[a] : make_float4(0.f, 0.f, 0.f, 2.f);
+        inst_w[4 * slot + a] = usable ? Wr[a] : make_float4(0.f, 0.f, 0.f, 2.f); // 64-B record: rows 0-2 = W, row 3 = live quarter (k_live)
         aabb[6 * i + a] = usable ? lo[a] : 3.0e38f;
         aabb[6 * i + 3 + a] = usable ? hi[a] : -3.0e38f;
     }
@@ -320,7 +320,7 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
     uint32_t cap = std::max<uint32_t>(n + n / 8, 256); // head-room: the reference grows by +75k far-field points
     dalloc(c->wnodes, (size_t)cap * EGR_WIDTH + 64);   // <= n-1 wide nodes (one per binary internal node, usually ~n/5)
     dalloc(c->pos_of_gid, cap);
-    dalloc(c->inst_w, 3 * (size_t)cap);
+    dalloc(c->inst_w, 4 * (size_t)cap);
     dalloc(c->inst_m, 3 * (size_t)cap);
     dalloc(c->app, 3 * (size_t)cap);
     dalloc(c->aabb, 6 * (size_t)cap);

@@ -31,9 +31,10 @@ inline void egr_hip_check(hipError_t e, const char *what) {
 #define EGR_HIP(expr) egr_hip_check((expr), #expr)
 
 // ---- per-Gaussian records (internal layout in HBM) -----------------------------------------------------
-// inst_w : float4[3N]   rows of W = M^-1 (world->object), snapshot at update/rebuild      48 B
+// inst_w : float4[4N]   64-B test record: rows of W = M^-1 (world->object; snapshot at update/rebuild) + live
+//                       quarter (f0.z, roughness, opacity, sigma) written per launch: one candidate test = one 64-B sector
 // inst_m : float4[3N]   rows of M   (object->world),      snapshot at update/rebuild      48 B
-// app    : float4[3N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y) (f0.z, rough, opacity, sigma) 48 B
+// app    : float4[2N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y)       32 B
 // wnodes : uint4[8*Nw]     8-wide BVH, one 128-B line per node; child slot (16 B):
 //          x = lo.x | lo.y<<16, y = lo.z | hi.x<<16, z = hi.y | hi.z<<16 (16-bit cells of the build frame), w = link
 // inst_w / inst_m / app are indexed by SORTED POSITION (Morton / leaf order), cluster j = positions [C*j, C*j+C);
@@ -96,6 +97,7 @@ enum ControlWord : int {
     CW_DBG = 32,        // optional traversal statistics (EGR_TRAVERSAL_STATS builds): 8 x 64-bit
     CW_DBG2 = 48,       // per-phase s_memtime sums: [primary traversal, primary composite, bounce traversal, bounce composite]
     CW_XQ = 64,         // XCD-affine task queues: [kernel 0..5][xcd 0..7] heads
+    CW_DBG3 = 112,      // per forward step: min / max wave exit time (s_memrealtime)
     CW_COUNT = 128
 };
 

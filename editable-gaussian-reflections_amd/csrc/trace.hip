@@ -88,7 +88,7 @@ struct LocalHit {
     f3 u;           // unscaled local hit
 };
 EGR_DI void object_ray(const float4 *__restrict__ inst_w, uint32_t gid, f3 o, f3 d, f3 &lo, f3 &ld) {
-    float4 w0 = inst_w[3 * gid], w1 = inst_w[3 * gid + 1], w2 = inst_w[3 * gid + 2];
+    float4 w0 = inst_w[4 * gid], w1 = inst_w[4 * gid + 1], w2 = inst_w[4 * gid + 2]; // 64-B records
     lo = mk3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
              w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
     ld = mk3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z, w2.x * d.x + w2.y * d.y + w2.z * d.z);
@@ -146,6 +146,8 @@ EGR_DI bool qslab_hit(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return t0 <= t1;
 }
+EGR_DI float4 fetch_a2(const float4 *p) { return *p; }
+EGR_DI float4 fetch_a2(float4 v) { return v; }
 // OptiX's instance test restated: segment [tmin,tmax] of the object-space ray vs the unit cube.
 EGR_DI bool hits_unit_cube(f3 lo, f3 ld, float tmin, float tmax) {
     f3 inv = mk3(__builtin_amdgcn_rcpf(ld.x), __builtin_amdgcn_rcpf(ld.y), __builtin_amdgcn_rcpf(ld.z)); // v_rcp_f32, 1 ulp
@@ -172,6 +174,7 @@ __global__ void k_prologue(DeviceView v, int grads) {
     if (t >= CW_DBG && t < CW_COUNT) v.control[t] = 0;
     if (t < 16) v.control[CW_DBG2 + t] = 0;
     if (t < 48) v.control[CW_XQ + t] = 0;
+    if (t < 12) v.control[CW_DBG3 + t] = ((t & 3) < 2) ? 0xFFFFFFFFu : 0u;
     if (t == 0) {
         *v.meta.grads_enabled = grads ? 1 : 0;   // metadata.h:29
         *v.meta.total_num_calls += 1;             // metadata.h:30
@@ -195,10 +198,12 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v) {
     const egr_gaussians &g = v.g;
     float o = sigmoid_act(g.opacity[i]);
     float sigma = compute_scaling_factor(o, *v.cfg.alpha_threshold, *v.cfg.exp_power);
-    float4 *app = const_cast<float4 *>(v.app) + 3 * (size_t)v.pos_of_gid[i]; // stored at the sorted position
+    const size_t pos = v.pos_of_gid[i]; // stored at the sorted position
+    float4 *app = const_cast<float4 *>(v.app) + 2 * pos;
     app[0] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
     app[1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
-    app[2] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
+    // the 4th quarter of the 64-B test record (rows of W are the first three): what a candidate test needs besides W
+    const_cast<float4 *>(v.inst_w)[4 * pos + 3] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -276,7 +281,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #endif
         // R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record.
         // `prim` is the gaussian's SORTED POSITION (record index), not its id.
-        auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, const float4 &a2) {
+        auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src) {
             const f3 lo = mk3(w0.x * ro.x + w0.y * ro.y + w0.z * ro.z + w0.w, w1.x * ro.x + w1.y * ro.y + w1.z * ro.z + w1.w,
                               w2.x * ro.x + w2.y * ro.y + w2.z * ro.z + w2.w);
             const f3 ld = mk3(w0.x * rd.x + w0.y * rd.y + w0.z * rd.z, w1.x * rd.x + w1.y * rd.y + w1.z * rd.z,
@@ -293,6 +298,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 f3 gn = mk3(v.g.normal[3 * gid], v.g.normal[3 * gid + 1], v.g.normal[3 * gid + 2]);
                 if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) return;
             }
+            const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
             f3 x = u * a2.w;                                          // :64
             float gaussval = eval_gaussian_sq(dot(x, x), exp_power);   // :65
             float alpha = EGR_MAX_ALPHA * gaussval * a2.z;             // kernel.cu:14-16
@@ -358,8 +364,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         st_leafhits += hit ? 1u : 0u;
                         st_outer += (lane == 0);
 #endif
-                        const float4 w0 = load_f4_uniform(v.inst_w, 3 * p), w1 = load_f4_uniform(v.inst_w, 3 * p + 1), w2 = load_f4_uniform(v.inst_w, 3 * p + 2);
-                        const float4 a2 = load_f4_uniform(app, 3 * p + 2);
+                        const float4 w0 = load_f4_uniform(v.inst_w, 4 * p), w1 = load_f4_uniform(v.inst_w, 4 * p + 1), w2 = load_f4_uniform(v.inst_w, 4 * p + 2);
+                        const float4 a2 = load_f4_uniform(v.inst_w, 4 * p + 3);
                         if (hit) evaluate(p, w0, w1, w2, a2);
                     } else {
                         if (lane == 0) ustk[usp] = sl.w;
@@ -380,7 +386,13 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 else overflow = true; // > 256 pending subtrees: cannot happen for trees the builder produces
             };
             if (ray_ok) push(0u);
+#ifdef EGR_TRAVERSAL_STATS
+            unsigned long long tA = 0, tB = 0;
+#endif
             for (;;) {
+#ifdef EGR_TRAVERSAL_STATS
+                const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+#endif
                 while (sp > 0 && nq + EGR_WIDTH <= v.cand_cap) { // phase A
                     sp--;
                     const uint32_t w = sp < EGR_LSTK ? lstk[sp][lane] : gstk[(size_t)(sp - EGR_LSTK) * EGR_WAVE + lane];
@@ -402,19 +414,30 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 }
 #ifdef EGR_TRAVERSAL_STATS
                 st_leafhits += nq;
+                const unsigned long long ta1 = __builtin_amdgcn_s_memtime();
+                tA += ta1 - ta0;
 #endif
                 for (uint32_t q = 0; q < nq; q++) { // phase B
                     const uint32_t p = queue[(size_t)q * EGR_WAVE + lane];
 #ifdef EGR_TRAVERSAL_STATS
                     st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
 #endif
-                    const float4 w0 = v.inst_w[3 * p], w1 = v.inst_w[3 * p + 1], w2 = v.inst_w[3 * p + 2];
-                    const float4 a2 = app[3 * p + 2];
-                    evaluate(p, w0, w1, w2, a2);
+                    // one 64-B record per candidate: rows of W, then (f0.z, rough, opacity, sigma) - fetched only on acceptance
+                    const float4 w0 = v.inst_w[4 * p], w1 = v.inst_w[4 * p + 1], w2 = v.inst_w[4 * p + 2];
+                    evaluate(p, w0, w1, w2, v.inst_w + 4 * (size_t)p + 3);
                 }
                 nq = 0;
+#ifdef EGR_TRAVERSAL_STATS
+                tB += __builtin_amdgcn_s_memtime() - ta1;
+#endif
                 if (__ballot(sp > 0) == 0ull) break;
             }
+#ifdef EGR_TRAVERSAL_STATS
+            if (lane == 0) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0)), tA);
+                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0) + 2), tB);
+            }
+#endif
         }
 
 #ifdef EGR_TRAVERSAL_STATS
@@ -478,7 +501,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                     float2 av = vals[(size_t)bi * EGR_WAVE + lane];
                     float alpha = av.x;
                     uint32_t pos = f2u(av.y); // record index (sorted position)
-                    float4 a0 = app[3 * pos], a1 = app[3 * pos + 1], a2 = app[3 * pos + 2];
+                    float4 a0 = app[2 * pos], a1 = app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
                     float next_T = T * (1.0f - alpha);       // :108
                     float weight = T - next_T;               // :109
                     c_rgb = c_rgb + mk3(a0.x, a0.y, a0.z) * weight;
@@ -528,6 +551,13 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         w_cand += active ? traversed : 0u;
         w_comp += active ? nhits : 0u;
     }
+#ifdef EGR_TRAVERSAL_STATS
+    if (lane == 0) { // exit-time spread of the persistent waves (s_memrealtime: constant 100 MHz)
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        atomicMin(reinterpret_cast<unsigned long long *>(v.control + CW_DBG3 + 4 * step), now);
+        atomicMax(reinterpret_cast<unsigned long long *>(v.control + CW_DBG3 + 4 * step + 2), now);
+    }
+#endif
     w_rays = wave_sum_u32(w_rays), w_cand = wave_sum_u32(w_cand), w_comp = wave_sum_u32(w_comp);
     if (lane == 0) add64(v.control, CW_RAYS + 2 * step, w_rays), add64(v.control, CW_CAND + 2 * step, w_cand), add64(v.control, CW_COMP + 2 * step, w_comp);
 }
@@ -647,7 +677,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     const uint32_t pos = f2u(rec.x);          // record index (sorted position)
                     const uint32_t gid = v.gid_of_pos[pos];   // the caller's gaussian id (parameter / gradient index)
                     const float distance = rec.y, alpha = rec.z, transmittance = rec.w;
-                    const float4 a0 = v.app[3 * pos], a1 = v.app[3 * pos + 1], a2 = v.app[3 * pos + 2];
+                    const float4 a0 = v.app[2 * pos], a1 = v.app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
                     const f3 g_rgb = mk3(a0.x, a0.y, a0.z);
                     const float opacity = a2.z, scaling_factor = a2.w;
                     // recompute the local hit exactly as the forward did
@@ -697,7 +727,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     const float dL_dgaussval = EGR_MAX_ALPHA * dL_dalpha * opacity; // :155-158
                     const float dL_dsq_norm = gaussval * pow_exp_m1(sq_norm, exp_power);
                     const f3 dL_dx_local = (-local_hit * dL_dsq_norm) * dL_dgaussval;
-                    const float4 W0 = v.inst_w[3 * pos], W1 = v.inst_w[3 * pos + 1], W2 = v.inst_w[3 * pos + 2];
+                    const float4 W0 = v.inst_w[4 * pos], W1 = v.inst_w[4 * pos + 1], W2 = v.inst_w[4 * pos + 2];
                     const f3 dL_dx_world = mk3(dot(mk3(W0.x, W1.x, W2.x), dL_dx_local), dot(mk3(W0.y, W1.y, W2.y), dL_dx_local),
                                                dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
                     const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;

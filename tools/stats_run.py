@@ -7,3 +7,10 @@ rt=ren.GaussianRaytracer(pc,W,H,ppll_forward_size=400_000_000,ppll_backward_size
 camera=ren.camera_from_c2w(cam["origin"],cam["c2w"],cam["fov"])
 with torch.no_grad(): rt(camera)
 c=m.get_counters(); print("rays",c[0:3],"Hc",[c[3+i]/max(c[i],1) for i in range(3)],"Kc",[c[6+i]/max(c[i],1) for i in range(3)])
+st = m.get_stats().num_traversed_per_pixel.float().flatten()
+q = torch.tensor([0.5, 0.9, 0.99, 0.999, 0.9999], device=st.device)
+idx = (q * (st.numel() - 1)).long()
+ss = st.sort().values
+print("Hc per pixel (all steps) quantiles 50/90/99/99.9/99.99%:", ss[idx].tolist(), "max", float(ss[-1]), "mean", float(st.mean()))
+t = st.view(H // 8, 8, W // 8, 8).amax(dim=(1, 3)).flatten().sort().values
+print("per-tile max-lane Hc quantiles:", t[(q * (t.numel() - 1)).long()].tolist(), "max", float(t[-1]), "mean of tile max", float(t.mean()))
