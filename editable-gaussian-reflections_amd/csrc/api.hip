@@ -63,6 +63,7 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     c->device = device, c->width = width, c->height = height;
     c->fwd_capacity = ppll_forward_size > 0 ? ppll_forward_size : 1, c->bwd_capacity = ppll_backward_size > 0 ? ppll_backward_size : 1;
     if (const char *e = getenv("EGR_PACKET_MODE")) c->packet_mode = atoi(e);           // tuning knobs
+    if (const char *e = getenv("EGR_BUCKETED_BACKWARD")) c->bucketed_backward = atoi(e);
     if (const char *e = getenv("EGR_GROUP_LANES")) {
         int g = atoi(e);
         if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) c->group_lanes = (uint32_t)g;
@@ -106,7 +107,10 @@ int egr_set_gaussians(egr_context *c, const egr_gaussians *g) {
     if (!c || !g) return 1;
     c->g = *g;
     c->have_gaussians = true;
-    return guarded(c, [&] { egr_bvh_reserve(c, g->count); });
+    return guarded(c, [&] {
+        egr_bvh_reserve(c, g->count);
+        egr_trace_reserve_buckets(c, g->count);
+    });
 }
 
 int egr_set_partition(egr_context *c, int rank, int world) {

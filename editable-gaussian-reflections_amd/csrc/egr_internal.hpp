@@ -16,6 +16,7 @@
 #define EGR_LEAF_FLAG 0x80000000u  // child slot link: leaf -> EGR_LEAF_FLAG | record index, internal -> child node index
 #define EGR_EMPTY_SLOT 0xFFFFFFFFu // unused child slot (checked before the leaf flag)
 #define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
+#define EGR_BUCKET_SHIFT 8         // gradient buckets of 256 Morton-consecutive gaussians (bounce-step backward)
 #define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
 #define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
 #define EGR_HIT_BLOCK_ROWS 8  // composited-hit arena block: 8 rows x 64 lanes x 16 B (+1 header row)
@@ -81,6 +82,9 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t *control;     // device counters (see ControlWord)
     int packet_mode;       // 0 per-lane walk only, 1 packet walk for primary rays, 2 adaptive (coherence test per tile)
     float packet_cos_min, packet_origin_max;
+    float4 *gb_data;       // [buckets][gb_cap][4] 64-B gradient records of the bounce-step backward
+    uint32_t *gb_count;    // [buckets]
+    uint32_t gb_cap;
     uint32_t group_lanes;  // lanes that walk the tree in lockstep on the non-packet path (power of two, 1..64)
 };
 
@@ -142,6 +146,9 @@ struct egr_context {
     float *cand_keys = nullptr;
     float2 *cand_vals = nullptr;
     uint32_t *cand_queue = nullptr, *stack_spill = nullptr;
+    float4 *gb_data = nullptr;
+    uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
+    int bucketed_backward = 1;
     uint32_t cand_cap = 0, num_slots = 0;
     float4 *hit_arena = nullptr;
     uint32_t hit_blocks_cap = 0;
@@ -176,6 +183,7 @@ void egr_trace_free(egr_context *c);
 void egr_trace_launch(egr_context *c, bool grads, hipStream_t s);
 uint32_t egr_num_tasks_for_rank(const egr_context *c);
 void egr_build_task_order(egr_context *c);
+void egr_trace_reserve_buckets(egr_context *c, uint32_t n);
 DeviceView egr_make_view(const egr_context *c);
 // timing helpers (api.hip)
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s);

@@ -573,15 +573,37 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #define EGR_GT_EMPTY 0xFFFFFFFFu
 enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_NORMAL = 14, GC_F0 = 17, GC_ROUGH = 20, GC_WEIGHT = 21 };
 
-EGR_DI void grad_table_flush(const egr_gaussians &g, uint32_t *gt_keys, float *gt_vals, int lane) {
+// Bounce steps: a tile's rays scatter over hundreds of distinct gaussians and the device runs at its fp32-atomic rate
+// (~26 G/s measured) if every contribution is a global atomic. Instead ONE 64-B record per (tile, gaussian) - or per hit
+// when the LDS table is full - is appended to the bucket of its gaussian (256 Morton-consecutive gaussians, one returning
+// counter atomic); k_bucket_reduce then sums each bucket in LDS and writes the gradients without global atomics.
+EGR_DI bool bucket_append(const DeviceView &v, uint32_t pos, float d_opacity, f3 d_scale, f3 d_mean, float r0, float r1, float r2, float r3,
+                          f3 d_rgb, float weight) {
+    const uint32_t bucket = pos >> EGR_BUCKET_SHIFT;
+    const uint32_t at = atomicAdd(v.gb_count + bucket, 1u);
+    if (at >= v.gb_cap) return false; // bucket full: the caller falls back to atomics (correct, slower)
+    float4 *dst = v.gb_data + ((size_t)bucket * v.gb_cap + at) * 4;
+    dst[0] = make_float4(u2f(pos & ((1u << EGR_BUCKET_SHIFT) - 1u)), d_opacity, d_scale.x, d_scale.y);
+    dst[1] = make_float4(d_scale.z, d_mean.x, d_mean.y, d_mean.z);
+    dst[2] = make_float4(r0, r1, r2, r3);
+    dst[3] = make_float4(d_rgb.x, d_rgb.y, d_rgb.z, weight);
+    return true;
+}
+
+EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_keys, float *gt_vals, int lane) {
+    const egr_gaussians &g = v.g;
     __syncthreads();
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) {
-        const uint32_t gid = gt_keys[s];
-        if (gid == EGR_GT_EMPTY) continue;
+        const uint32_t pos = gt_keys[s];
+        if (pos == EGR_GT_EMPTY) continue;
         gt_keys[s] = EGR_GT_EMPTY;
         float x[EGR_GT_COMPS];
 #pragma unroll
         for (int c = 0; c < EGR_GT_COMPS; c++) x[c] = gt_vals[c * EGR_GT_SLOTS + s], gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
+        if (bucketed && bucket_append(v, pos, x[GC_OPA], mk3(x[GC_SCALE], x[GC_SCALE + 1], x[GC_SCALE + 2]), mk3(x[GC_MEAN], x[GC_MEAN + 1], x[GC_MEAN + 2]),
+                                      x[GC_ROT], x[GC_ROT + 1], x[GC_ROT + 2], x[GC_ROT + 3], mk3(x[GC_RGB], x[GC_RGB + 1], x[GC_RGB + 2]), x[GC_WEIGHT]))
+            continue; // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
+        const uint32_t gid = v.gid_of_pos[pos];
 #define EGR_FL(ptr, idx, c) if (x[c] != 0.0f) atomicAdd(&(ptr)[idx], x[c]);
         EGR_FL(g.dL_dopacity, gid, GC_OPA)
         EGR_FL(g.dL_dscale, 3 * gid, GC_SCALE) EGR_FL(g.dL_dscale, 3 * gid + 1, GC_SCALE + 1) EGR_FL(g.dL_dscale, 3 * gid + 2, GC_SCALE + 2)
@@ -609,6 +631,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
     if (step > num_bounces) return;
     const egr_gaussians &g = v.g;
     uint32_t cur_q = blockIdx.x & 7u;
+    const bool bucketed = step > 0 && v.gb_data != nullptr;
 
     for (;;) {
         const uint32_t task = wave_next_task(v.control + CW_XQ + 8 * (3 + step), v.num_tasks, cur_q);
@@ -752,12 +775,12 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     // :210-220 flush: into the LDS table when a slot is found within 8 probes, else straight to global
                     const float d_rot0 = dd * -qu.x * inv3 + dL_dr * inv1, d_rot1 = dd * -qu.y * inv3 + dL_dx * inv1;
                     const float d_rot2 = dd * -qu.z * inv3 + dL_dy * inv1, d_rot3 = dd * -qu.w * inv3 + dL_dz * inv1;
-                    uint32_t slot = (gid * 2654435761u) >> 25; // top 7 bits -> [0,128)
+                    uint32_t slot = (pos * 2654435761u) >> 25; // top 7 bits -> [0,128); keyed by record index
                     bool found = false;
 #pragma unroll 1
                     for (int probe = 0; probe < 8; probe++) {
-                        const uint32_t old = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, gid);
-                        if (old == EGR_GT_EMPTY || old == gid) { found = true; break; }
+                        const uint32_t old = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, pos);
+                        if (old == EGR_GT_EMPTY || old == pos) { found = true; break; }
                         slot = (slot + 1) & (EGR_GT_SLOTS - 1);
                     }
                     if (found) {
@@ -773,6 +796,8 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                         }
                         EGR_TA(GC_WEIGHT, weight)
 #undef EGR_TA
+                    } else if (bucketed && bucket_append(v, pos, d_opacity, d_scale, d_mean, d_rot0, d_rot1, d_rot2, d_rot3, d_rgb, weight)) {
+                        // table full for this gaussian: straight to its bucket
                     } else {
                         atomicAdd(&g.dL_dopacity[gid], d_opacity);
                         atomicAdd(&g.dL_dscale[3 * gid], d_scale.x), atomicAdd(&g.dL_dscale[3 * gid + 1], d_scale.y), atomicAdd(&g.dL_dscale[3 * gid + 2], d_scale.z);
@@ -792,7 +817,46 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
             blk = f2u(rows[0].x); // header: previous (older) block of this task
         }
         (void)new_slots;
-        grad_table_flush(g, gt_keys, gt_vals, lane); // one flush per tile; probe overflow already went to global
+        grad_table_flush(v, bucketed, gt_keys, gt_vals, lane); // one flush per tile
+    }
+}
+
+// Second half of the bucketed bounce backward: one workgroup per bucket sums the bucket's records in LDS (ds_add_f32) and
+// adds the totals to the gradient tensors with plain read-modify-writes (a gaussian belongs to exactly one bucket and
+// no other kernel touches the gradients concurrently - stream order).
+__global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
+    constexpr int BG = 1 << EGR_BUCKET_SHIFT; // gaussians per bucket
+    __shared__ float acc[15][BG];
+    const uint32_t bucket = blockIdx.x;
+    const uint32_t count = min(v.gb_count[bucket], v.gb_cap);
+    if (count == 0) return;
+    __syncthreads();
+    if (threadIdx.x == 0) v.gb_count[bucket] = 0; // empty for the next step
+    for (int i = threadIdx.x; i < 15 * BG; i += 256) (&acc[0][0])[i] = 0.0f;
+    __syncthreads();
+    const float4 *src = v.gb_data + (size_t)bucket * v.gb_cap * 4;
+    for (uint32_t r = threadIdx.x; r < count; r += 256) {
+        const float4 a = src[4 * (size_t)r], b = src[4 * (size_t)r + 1], c = src[4 * (size_t)r + 2], d = src[4 * (size_t)r + 3];
+        const uint32_t l = f2u(a.x);
+        atomicAdd(&acc[0][l], a.y), atomicAdd(&acc[1][l], a.z), atomicAdd(&acc[2][l], a.w), atomicAdd(&acc[3][l], b.x);
+        atomicAdd(&acc[4][l], b.y), atomicAdd(&acc[5][l], b.z), atomicAdd(&acc[6][l], b.w);
+        atomicAdd(&acc[7][l], c.x), atomicAdd(&acc[8][l], c.y), atomicAdd(&acc[9][l], c.z), atomicAdd(&acc[10][l], c.w);
+        atomicAdd(&acc[11][l], d.x), atomicAdd(&acc[12][l], d.y), atomicAdd(&acc[13][l], d.z), atomicAdd(&acc[14][l], d.w);
+    }
+    __syncthreads();
+    const uint32_t pos = bucket * BG + threadIdx.x;
+    if (threadIdx.x < BG && pos < v.n) {
+        const uint32_t l = threadIdx.x;
+        if (acc[14][l] != 0.0f || acc[0][l] != 0.0f) {
+            const uint32_t gid = v.gid_of_pos[pos];
+            const egr_gaussians &g = v.g;
+            g.dL_dopacity[gid] += acc[0][l];
+            g.dL_dscale[3 * gid] += acc[1][l], g.dL_dscale[3 * gid + 1] += acc[2][l], g.dL_dscale[3 * gid + 2] += acc[3][l];
+            g.dL_dmean[3 * gid] += acc[4][l], g.dL_dmean[3 * gid + 1] += acc[5][l], g.dL_dmean[3 * gid + 2] += acc[6][l];
+            g.dL_drotation[4 * gid] += acc[7][l], g.dL_drotation[4 * gid + 1] += acc[8][l], g.dL_drotation[4 * gid + 2] += acc[9][l], g.dL_drotation[4 * gid + 3] += acc[10][l];
+            g.dL_drgb[3 * gid] += acc[11][l], g.dL_drgb[3 * gid + 1] += acc[12][l], g.dL_drgb[3 * gid + 2] += acc[13][l];
+            g.total_weight[gid] += acc[14][l];
+        }
     }
 }
 
@@ -885,7 +949,7 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
+    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
     if (c->control_host) (void)hipHostFree(c->control_host);
     c->control_host = nullptr;
 }
@@ -911,6 +975,7 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->cand_queue, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
     EGR_HIP(hipMalloc((void **)&c->stack_spill, (size_t)c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
     double bwd_bytes = (double)c->bwd_capacity * 36.0;
+    if (c->bucketed_backward) bwd_bytes *= 0.25; // the rest holds the gradient buckets
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
     EGR_HIP(hipMalloc((void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
@@ -923,6 +988,22 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipHostMalloc((void **)&c->control_host, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipMalloc((void **)&c->task_macro, std::max<size_t>(c->num_tasks_total / 4, 1) * sizeof(uint32_t)));
     egr_build_task_order(c);
+}
+
+// Bucket storage for the bounce-step backward: half of the backward byte budget (ppll_backward_size x 36 B), split
+// evenly over the buckets; a bucket that overflows falls back to atomics for the excess (correct, slower).
+void egr_trace_reserve_buckets(egr_context *c, uint32_t n) {
+    const uint32_t nb = (n + (1u << EGR_BUCKET_SHIFT) - 1u) >> EGR_BUCKET_SHIFT;
+    if (!c->bucketed_backward || nb == 0) return;
+    if (nb <= c->gb_buckets_alloc && c->gb_data) return;
+    dfree(c->gb_data), dfree(c->gb_count);
+    const uint32_t nb_alloc = nb + nb / 8 + 1;
+    const double bytes = (double)c->bwd_capacity * 36.0 * 0.75;
+    uint64_t cap = (uint64_t)(bytes / 64.0 / (double)nb_alloc);
+    c->gb_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 1u << 22);
+    EGR_HIP(hipMalloc((void **)&c->gb_data, (size_t)nb_alloc * c->gb_cap * 64));
+    EGR_HIP(hipMalloc((void **)&c->gb_count, (size_t)nb_alloc * sizeof(uint32_t)));
+    c->gb_buckets_alloc = nb_alloc;
 }
 
 DeviceView egr_make_view(const egr_context *c) {
@@ -942,6 +1023,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
     v.group_lanes = c->group_lanes;
+    v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
     return v;
 }
 
@@ -965,10 +1047,17 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             egr_stamp_end(c, s);
         }
         if (grads) {
+            const uint32_t nbuckets = (v.n + (1u << EGR_BUCKET_SHIFT) - 1u) >> EGR_BUCKET_SHIFT;
+            if (v.gb_data && nbuckets) EGR_HIP(hipMemsetAsync(v.gb_count, 0, nbuckets * sizeof(uint32_t), s));
             for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
                 egr_stamp_begin(c, bn[step], s);
                 hipLaunchKernelGGL(k_backward, grid, block, 0, s, v, step);
                 egr_stamp_end(c, s);
+                if (step >= 1 && v.gb_data && nbuckets) { // reduce (and empty) the buckets after every bounce step
+                    egr_stamp_begin(c, step == 1 ? "backward_bucket_reduce1" : "backward_bucket_reduce2", s);
+                    hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets), dim3(256), 0, s, v);
+                    egr_stamp_end(c, s);
+                }
             }
         } else {
             egr_stamp_begin(c, "write_outputs", s);
