@@ -70,8 +70,9 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
         float W0 = R[0][a] * inv[a], W1 = R[1][a] * inv[a], W2 = R[2][a] * inv[a];
         Wr[a] = make_float4(W0, W1, W2, -(W0 * m[0] + W1 * m[1] + W2 * m[2]));
         finite = finite && isfinite(W0 + W1 + W2 + Wr[a].w);
-        float ext = fabsf(M0) + fabsf(M1) + fabsf(M2);
-        // boxes only prune; candidacy is decided by the exact object-space cube test. Pad against fp32 rounding.
+        // Box of the ELLIPSOID M * (unit sphere): half-extent = |row of M|_2 (not the cube's |row|_1). Accepted hits have
+        // their response point inside it (see the three-segment walk in trace.hip); padded against fp32 rounding.
+        float ext = sqrtf(M0 * M0 + M1 * M1 + M2 * M2);
         ext = ext * 1.0001f + 4e-7f * (fabsf(m[a]) + ext);
         lo[a] = m[a] - ext;
         hi[a] = m[a] + ext;

@@ -279,6 +279,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #ifdef EGR_TRAVERSAL_STATS
         uint32_t st_visits = 0, st_leafhits = 0, st_inner = 0, st_outer = 0;
 #endif
+        int seg = 0;                 // which of the three walked segments is active (see the walk below)
+        float seg_lo, seg_hi;
         // R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record.
         // `prim` is the gaussian's SORTED POSITION (record index), not its id.
         auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src) {
@@ -287,11 +289,13 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             const f3 ld = mk3(w0.x * rd.x + w0.y * rd.y + w0.z * rd.z, w1.x * rd.x + w1.y * rd.y + w1.z * rd.z,
                               w2.x * rd.x + w2.y * rd.y + w2.z * rd.z);
             if (!hits_unit_cube(lo, ld, near_plane, far_plane)) return;
-            traversed++;                                    // shaders.cu:33
-            if (dot(lo, ld) > 0.0f) return;                 // :36
             f3 dhat, u;
             float t;
             closest_point(lo, ld, dhat, t, u);              // :41-45
+            // each candidate is owned by exactly one of the three walked segments (see below): counted / accepted once
+            if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return;
+            traversed++;                                    // shaders.cu:33 (evaluations that reached the intersection program)
+            if (dot(lo, ld) > 0.0f) return;                 // :36
             if (dot(u, u) > 1.0f) return;                   // :48-51
             if (step != 0 && t < backfacing_max_dist) {     // :54-61 (world normal . object dir)
                 const uint32_t gid = v.gid_of_pos[prim];
@@ -333,6 +337,21 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             packet = v.packet_mode == 2 ? (cmin >= v.packet_cos_min && omax <= v.packet_origin_max) : (v.packet_mode == 1 && step == 0);
             packet = __builtin_amdgcn_readfirstlane(packet ? 1 : 0) != 0;
         }
+        // The tree bounds each gaussian's ELLIPSOID (image of the unit sphere), not its cube: an accepted hit's response
+        // point lies inside the ellipsoid (|u|^2 <= 1, shaders.cu:48), so walking a segment finds every accepted hit whose
+        // response point lies on that segment, with far fewer false-positive record fetches than cube boxes (the walk is
+        // bound by random cache-line fetches). The reference also accepts hits whose response point lies OUTSIDE
+        // [tmin,tmax] as long as the cube overlaps the segment (quirk Q1): those are exactly the hits found by walking
+        // [0,tmin) and (tmax,inf) and keeping the ones whose cube still overlaps [tmin,tmax] (the cube test below always
+        // uses the launch's near/far planes). Three disjoint ownership ranges -> every accepted candidate counted once.
+        seg_lo = near_plane, seg_hi = far_plane;
+        for (seg = 0; seg < 3; seg++) {
+            if (seg == 1) {
+                if (!(near_plane > 0.0f)) continue; // bounce steps start at 0: nothing before the segment
+                seg_lo = 0.0f, seg_hi = near_plane;
+            } else if (seg == 2) {
+                seg_lo = far_plane, seg_hi = 3.0e38f;
+            }
         if (packet) {
             // ---- packet walk: wave-uniform DFS over the 8-wide tree; stack in LDS (uniform address), node slots, leaf
             // transforms and live records through the scalar cache; each lane tests its own ray, a child is entered /
@@ -353,7 +372,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 for (int k = 0; k < EGR_WIDTH; k++) {
                     const uint4 sl = load_u4_uniform(wnodes, w * EGR_WIDTH + (uint32_t)k);
                     if (sl.w == EGR_EMPTY_SLOT) break; // uniform: slots are packed from 0
-                    const bool hit = ray_ok && qslab_hit(sl, invq, ncq, near_plane, far_plane);
+                    const bool hit = ray_ok && qslab_hit(sl, invq, ncq, seg_lo, seg_hi);
                     if (__ballot(hit) == 0ull) continue;
 #ifdef EGR_TRAVERSAL_STATS
                     st_visits += hit ? 1u : 0u;
@@ -407,7 +426,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #pragma unroll
                     for (int k = EGR_WIDTH - 1; k >= 0; k--) { // reverse: slot 0 is popped first
                         if (sl[k].w == EGR_EMPTY_SLOT) continue;
-                        if (!qslab_hit(sl[k], invq, ncq, near_plane, far_plane)) continue;
+                        if (!qslab_hit(sl[k], invq, ncq, seg_lo, seg_hi)) continue;
                         if (sl[k].w & EGR_LEAF_FLAG) queue[(size_t)nq * EGR_WAVE + lane] = sl[k].w & ~EGR_LEAF_FLAG, nq++;
                         else push(sl[k].w);
                     }
@@ -440,6 +459,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #endif
         }
 
+        }
 #ifdef EGR_TRAVERSAL_STATS
         const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
         {
