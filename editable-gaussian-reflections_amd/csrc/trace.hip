@@ -477,33 +477,44 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             bool running = active && cnt > 0;
             uint32_t last_block = 0xFFFFFFFFu, cur_block = 0xFFFFFFFFu;
             bool recording = GRADS;
-            for (uint32_t it = 0;; it++) {
-                // strict successor of (t_prev, k_prev) in (t, k) lexicographic order
-                float best = 3.4028235e38f;
-                uint32_t bi = 0xFFFFFFFFu;
+            // Depth order in batches of 8 (= one arena block): ONE scan over the lane's key column keeps the 8 strict
+            // successors of (t_prev, k_prev) in (t, k) lexicographic order in registers (sorted insertion, static indices),
+            // then the batch is composited front to back. The old "one scan per composited hit" cost Kc+1 passes.
+            for (uint32_t it = 0;; it += EGR_HIT_BLOCK_ROWS) {
+                float kt[8];
+                uint32_t ki[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) kt[j] = 3.4028235e38f, ki[j] = 0xFFFFFFFFu;
                 if (running) {
-                    // the scan is a chain of independent, coalesced 256-B row loads: issue 8 before consuming any,
-                    // otherwise every iteration pays a full L2 round trip (measured: the scan was latency-bound)
+                    auto consider = [&](float tk, uint32_t k) {
+                        const bool after = (tk > t_prev) || (tk == t_prev && k > k_prev && k_prev != 0xFFFFFFFFu);
+                        if (after && tk < kt[7]) { // displaces the current 8th: bubble into place (stable: equal t keeps list order)
+                            float xt = tk;
+                            uint32_t xi = k;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const bool sw = xt < kt[j];
+                                const float ot = kt[j];
+                                const uint32_t oi = ki[j];
+                                kt[j] = sw ? xt : ot, ki[j] = sw ? xi : oi;
+                                xt = sw ? ot : xt, xi = sw ? oi : xi;
+                            }
+                        }
+                    };
+                    // coalesced 256-B row loads, 8 in flight before any is consumed (the scan is latency-bound otherwise)
                     uint32_t k = 0;
                     for (; k + 8 <= cnt; k += 8) {
                         float tk[8];
 #pragma unroll
                         for (int j = 0; j < 8; j++) tk[j] = keys[(size_t)(k + j) * EGR_WAVE + lane];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            bool after = (tk[j] > t_prev) || (tk[j] == t_prev && (k + j) > k_prev && k_prev != 0xFFFFFFFFu);
-                            if (after && tk[j] < best) best = tk[j], bi = k + j;
-                        }
+                        for (int j = 0; j < 8; j++) consider(tk[j], k + j);
                     }
-                    for (; k < cnt; k++) {
-                        float tk = keys[(size_t)k * EGR_WAVE + lane];
-                        bool after = (tk > t_prev) || (tk == t_prev && k > k_prev && k_prev != 0xFFFFFFFFu);
-                        if (after && tk < best) best = tk, bi = k;
-                    }
-                    if (bi == 0xFFFFFFFFu || !(best < far_plane)) running = false; // :81, :91-93
+                    for (; k < cnt; k++) consider(keys[(size_t)k * EGR_WAVE + lane], k);
+                    if (ki[0] == 0xFFFFFFFFu || !(kt[0] < far_plane)) running = false; // :81, :91-93
                 }
                 if (__ballot(running) == 0ull) break;
-                if (GRADS && (it % EGR_HIT_BLOCK_ROWS) == 0 && recording) { // one arena block per 8 rows per wave
+                if (GRADS && recording) { // one arena block per batch per wave
                     uint32_t blk = 0;
                     if (lane == 0) blk = atomicAdd(v.control + CW_HIT_BUMP, 1u);
                     blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
@@ -515,26 +526,30 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         last_block = cur_block = blk;
                     }
                 }
-                if (running) {
-                    t_prev = best;
-                    k_prev = bi;
-                    float2 av = vals[(size_t)bi * EGR_WAVE + lane];
-                    float alpha = av.x;
-                    uint32_t pos = f2u(av.y); // record index (sorted position)
-                    float4 a0 = app[2 * pos], a1 = app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
-                    float next_T = T * (1.0f - alpha);       // :108
-                    float weight = T - next_T;               // :109
-                    c_rgb = c_rgb + mk3(a0.x, a0.y, a0.z) * weight;
-                    c_n = c_n + mk3(a0.w, a1.x, a1.y) * weight;
-                    c_f0 = c_f0 + mk3(a1.z, a1.w, a2.x) * weight;
-                    c_rough += a2.y * weight;
-                    c_depth += best * weight;
-                    T = next_T;
-                    nhits++;
-                    if (GRADS && recording)
-                        v.hit_arena[((size_t)cur_block * (EGR_HIT_BLOCK_ROWS + 1) + 1 + (it % EGR_HIT_BLOCK_ROWS)) * EGR_WAVE + lane] =
-                            make_float4(u2f(pos), best, alpha, T);
-                    if (T < transmittance_threshold || nhits >= EGR_MAX_COMPOSITED_PER_RAY) running = false; // :131-134, :55
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (running && (ki[j] == 0xFFFFFFFFu || !(kt[j] < far_plane))) running = false; // list exhausted / beyond zfar
+                    if (running) {
+                        const float best = kt[j];
+                        t_prev = best;
+                        k_prev = ki[j];
+                        float2 av = vals[(size_t)ki[j] * EGR_WAVE + lane];
+                        float alpha = av.x;
+                        uint32_t pos = f2u(av.y); // record index (sorted position)
+                        float4 a0 = app[2 * pos], a1 = app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
+                        float next_T = T * (1.0f - alpha);       // :108
+                        float weight = T - next_T;               // :109
+                        c_rgb = c_rgb + mk3(a0.x, a0.y, a0.z) * weight;
+                        c_n = c_n + mk3(a0.w, a1.x, a1.y) * weight;
+                        c_f0 = c_f0 + mk3(a1.z, a1.w, a2.x) * weight;
+                        c_rough += a2.y * weight;
+                        c_depth += best * weight;
+                        T = next_T;
+                        nhits++;
+                        if (GRADS && recording)
+                            v.hit_arena[((size_t)cur_block * (EGR_HIT_BLOCK_ROWS + 1) + 1 + j) * EGR_WAVE + lane] = make_float4(u2f(pos), best, alpha, T);
+                        if (T < transmittance_threshold || nhits >= EGR_MAX_COMPOSITED_PER_RAY) running = false; // :131-134, :55
+                    }
                 }
             }
             if (GRADS) {
