@@ -242,7 +242,13 @@ int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, voi
             EGR_HIP(hipMemcpy(tmp.data(), src, n * stride * sizeof(float), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < n; i++) memcpy(dst + 12 * i, tmp.data() + stride * (size_t)pos[i], 12 * sizeof(float));
         };
-        if (M) unpermute(c->inst_m, M, 12);
+        if (M) { // backward records hold (M row, exp(scale)); the reported 3x4 transform carries the mean in column 3
+            unpermute(c->inst_m, M, 16);
+            std::vector<float> mean(3 * n);
+            EGR_HIP(hipMemcpy(mean.data(), c->g.mean, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; i++)
+                for (int a = 0; a < 3; a++) M[12 * i + 4 * a + 3] = mean[3 * i + a];
+        }
         if (W) unpermute(c->inst_w, W, 16);
         if (aabb) EGR_HIP(hipMemcpy(aabb, c->aabb, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
     });

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         float M0 = s[0] * R[a][0], M1 = s[1] * R[a][1], M2 = s[2] * R[a][2];
-        inst_m[3 * slot + a] = make_float4(M0, M1, M2, m[a]);
+        inst_m[4 * slot + a] = make_float4(M0, M1, M2, expf(g.scale[3 * i + a])); // .w: activated scale (backward_pass.cu:170)
         float W0 = R[0][a] * inv[a], W1 = R[1][a] * inv[a], W2 = R[2][a] * inv[a];
         Wr[a] = make_float4(W0, W1, W2, -(W0 * m[0] + W1 * m[1] + W2 * m[2]));
         finite = finite && isfinite(W0 + W1 + W2 + Wr[a].w);
@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
         hi[a] = m[a] + ext;
         finite = finite && (lo[a] <= hi[a]) && isfinite(lo[a]) && isfinite(hi[a]);
     }
+    inst_m[4 * slot + 3] = q4; // raw quaternion for the normalisation backward (activations.cu:66-73)
     const bool usable = visible && finite; // NaN / inf parameters can never be hit
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -308,7 +309,7 @@ template <class T> void dalloc(T *&p, size_t count) {
 } // namespace
 
 void egr_bvh_free(egr_context *c) {
-    dfree(c->wnodes), dfree(c->pos_of_gid), dfree(c->inst_w), dfree(c->inst_m), dfree(c->app), dfree(c->aabb);
+    dfree(c->wnodes), dfree(c->pos_of_gid), dfree(c->inst_w), dfree(c->inst_m), dfree(c->app), dfree(c->aabb), dfree(c->grad_rows);
     dfree(c->sort_tmp), dfree(c->keys_in), dfree(c->keys_out), dfree(c->vals_in), dfree(c->vals_out);
     dfree(c->k_left), dfree(c->k_right), dfree(c->k_parent), dfree(c->k_first), dfree(c->k_last), dfree(c->wide_of), dfree(c->scratch_u32);
     c->n_alloc = 0;
@@ -322,7 +323,9 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
     dalloc(c->wnodes, (size_t)cap * EGR_WIDTH + 64);   // <= n-1 wide nodes (one per binary internal node, usually ~n/5)
     dalloc(c->pos_of_gid, cap);
     dalloc(c->inst_w, 4 * (size_t)cap);
-    dalloc(c->inst_m, 3 * (size_t)cap);
+    dalloc(c->inst_m, 4 * (size_t)cap);
+    dalloc(c->grad_rows, 32 * (size_t)cap);
+    EGR_HIP(hipMemset(c->grad_rows, 0, 32 * (size_t)cap * sizeof(float)));
     dalloc(c->app, 3 * (size_t)cap);
     dalloc(c->aabb, 6 * (size_t)cap);
     dalloc(c->keys_in, cap), dalloc(c->keys_out, cap), dalloc(c->vals_in, cap), dalloc(c->vals_out, cap);

@@ -65,7 +65,8 @@ struct DeviceView { // everything a kernel needs, passed by value
     const uint32_t *pos_of_gid; // [n] inverse
     BvhFrame frame;
     const float4 *inst_w;
-    const float4 *inst_m;
+    const float4 *inst_m;       // [n][4] backward record: rows 0-2 = (M row, exp(scale_a)), row 3 = raw quaternion
+    float *grad_rows;           // [n][32] gradient accumulation rows in record order (one 128-B line per gaussian)
     const float4 *app;
     // per-launch scratch
     float *cand_keys;      // [slots][cand_cap][64]
@@ -133,6 +134,7 @@ struct egr_context {
     BvhFrame frame{0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
     float4 *inst_w = nullptr, *inst_m = nullptr, *app = nullptr;
     float *aabb = nullptr;             // [n][6] instance boxes (lo, hi)
+    float *grad_rows = nullptr;        // [n_alloc][32] zero between launches (k_grad_gather empties what it reads)
     uint32_t max_depth = 0;
     // build temporaries
     void *sort_tmp = nullptr;

@@ -298,8 +298,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             if (dot(lo, ld) > 0.0f) return;                 // :36
             if (dot(u, u) > 1.0f) return;                   // :48-51
             if (step != 0 && t < backfacing_max_dist) {     // :54-61 (world normal . object dir)
-                const uint32_t gid = v.gid_of_pos[prim];
-                f3 gn = mk3(v.g.normal[3 * gid], v.g.normal[3 * gid + 1], v.g.normal[3 * gid + 2]);
+                const float4 n0 = app[2 * prim], n1 = app[2 * prim + 1]; // raw normal, record order (k_live)
+                f3 gn = mk3(n0.w, n1.x, n1.y);
                 if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) return;
             }
             const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
@@ -606,7 +606,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #define EGR_GT_SLOTS 128
 #define EGR_GT_COMPS 22
 #define EGR_GT_EMPTY 0xFFFFFFFFu
-enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_NORMAL = 14, GC_F0 = 17, GC_ROUGH = 20, GC_WEIGHT = 21 };
+// component order of the LDS table, of a bucket record (first 15) and of a gradient row (DeviceView::grad_rows)
+enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_WEIGHT = 14, GC_NORMAL = 15, GC_F0 = 18, GC_ROUGH = 21 };
+#define EGR_ROW_STRIDE 32 // floats per gradient row: one 128-B line per gaussian
 
 // Bounce steps: a tile's rays scatter over hundreds of distinct gaussians and the device runs at its fp32-atomic rate
 // (~26 G/s measured) if every contribution is a global atomic. Instead ONE 64-B record per (tile, gaussian) - or per hit
@@ -626,7 +628,6 @@ EGR_DI bool bucket_append(const DeviceView &v, uint32_t pos, float d_opacity, f3
 }
 
 EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_keys, float *gt_vals, int lane) {
-    const egr_gaussians &g = v.g;
     __syncthreads();
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) {
         const uint32_t pos = gt_keys[s];
@@ -638,17 +639,10 @@ EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_ke
         if (bucketed && bucket_append(v, pos, x[GC_OPA], mk3(x[GC_SCALE], x[GC_SCALE + 1], x[GC_SCALE + 2]), mk3(x[GC_MEAN], x[GC_MEAN + 1], x[GC_MEAN + 2]),
                                       x[GC_ROT], x[GC_ROT + 1], x[GC_ROT + 2], x[GC_ROT + 3], mk3(x[GC_RGB], x[GC_RGB + 1], x[GC_RGB + 2]), x[GC_WEIGHT]))
             continue; // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
-        const uint32_t gid = v.gid_of_pos[pos];
-#define EGR_FL(ptr, idx, c) if (x[c] != 0.0f) atomicAdd(&(ptr)[idx], x[c]);
-        EGR_FL(g.dL_dopacity, gid, GC_OPA)
-        EGR_FL(g.dL_dscale, 3 * gid, GC_SCALE) EGR_FL(g.dL_dscale, 3 * gid + 1, GC_SCALE + 1) EGR_FL(g.dL_dscale, 3 * gid + 2, GC_SCALE + 2)
-        EGR_FL(g.dL_dmean, 3 * gid, GC_MEAN) EGR_FL(g.dL_dmean, 3 * gid + 1, GC_MEAN + 1) EGR_FL(g.dL_dmean, 3 * gid + 2, GC_MEAN + 2)
-        EGR_FL(g.dL_drotation, 4 * gid, GC_ROT) EGR_FL(g.dL_drotation, 4 * gid + 1, GC_ROT + 1) EGR_FL(g.dL_drotation, 4 * gid + 2, GC_ROT + 2) EGR_FL(g.dL_drotation, 4 * gid + 3, GC_ROT + 3)
-        EGR_FL(g.dL_drgb, 3 * gid, GC_RGB) EGR_FL(g.dL_drgb, 3 * gid + 1, GC_RGB + 1) EGR_FL(g.dL_drgb, 3 * gid + 2, GC_RGB + 2)
-        EGR_FL(g.dL_dnormal, 3 * gid, GC_NORMAL) EGR_FL(g.dL_dnormal, 3 * gid + 1, GC_NORMAL + 1) EGR_FL(g.dL_dnormal, 3 * gid + 2, GC_NORMAL + 2)
-        EGR_FL(g.dL_df0, 3 * gid, GC_F0) EGR_FL(g.dL_df0, 3 * gid + 1, GC_F0 + 1) EGR_FL(g.dL_df0, 3 * gid + 2, GC_F0 + 2)
-        EGR_FL(g.dL_droughness, gid, GC_ROUGH) EGR_FL(g.total_weight, gid, GC_WEIGHT)
-#undef EGR_FL
+        float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all 22 components of a gaussian share one line
+#pragma unroll
+        for (int c = 0; c < EGR_GT_COMPS; c++)
+            if (x[c] != 0.0f) atomicAdd(row + c, x[c]);
     }
     __syncthreads();
 }
@@ -733,7 +727,6 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                 if (it < nhits) {
                     const float4 rec = rows[(size_t)(1 + row) * EGR_WAVE + lane];
                     const uint32_t pos = f2u(rec.x);          // record index (sorted position)
-                    const uint32_t gid = v.gid_of_pos[pos];   // the caller's gaussian id (parameter / gradient index)
                     const float distance = rec.y, alpha = rec.z, transmittance = rec.w;
                     const float4 a0 = v.app[2 * pos], a1 = v.app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
                     const f3 g_rgb = mk3(a0.x, a0.y, a0.z);
@@ -790,14 +783,13 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                                                dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
                     const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
                     const f3 d_mean = -dL_dx_world;
-                    const f3 scaling = mk3(expf(g.scale[3 * gid]), expf(g.scale[3 * gid + 1]), expf(g.scale[3 * gid + 2]));
+                    const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3];
+                    const f3 scaling = mk3(M0.w, M1.w, M2.w); // exp(scale), stored by k_instances
                     const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
                                        scaling.z * scaling_factor + eps_scale_grad);
-                    const float4 M0 = v.inst_m[3 * pos], M1 = v.inst_m[3 * pos + 1], M2 = v.inst_m[3 * pos + 2];
                     const f3 rot_0 = mk3(M0.x, M0.y, M0.z) / den, rot_1 = mk3(M1.x, M1.y, M1.z) / den, rot_2 = mk3(M2.x, M2.y, M2.z) / den; // :178-180
                     const f3 d_scale = (dl2w0 * rot_0 + dl2w1 * rot_1 + dl2w2 * rot_2) * scaling; // :181-182
                     const f3 dr0 = dl2w0 * scaling, dr1 = dl2w1 * scaling, dr2 = dl2w2 * scaling; // :185-187
-                    const float4 qu = reinterpret_cast<const float4 *>(g.rotation)[gid];
                     const float qn = sqrtf(qu.x * qu.x + qu.y * qu.y + qu.z * qu.z + qu.w * qu.w);
                     const float r = qu.x / qn, x = qu.y / qn, y = qu.z / qn, z = qu.w / qn; // activations.cu:66-69
                     const float dL_dr = 2.f * x * (dr2.y - dr1.z) + 2.f * y * (dr0.z - dr2.x) + 2.f * z * (dr1.x - dr0.y); // :194-205
@@ -834,18 +826,18 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                     } else if (bucketed && bucket_append(v, pos, d_opacity, d_scale, d_mean, d_rot0, d_rot1, d_rot2, d_rot3, d_rgb, weight)) {
                         // table full for this gaussian: straight to its bucket
                     } else {
-                        atomicAdd(&g.dL_dopacity[gid], d_opacity);
-                        atomicAdd(&g.dL_dscale[3 * gid], d_scale.x), atomicAdd(&g.dL_dscale[3 * gid + 1], d_scale.y), atomicAdd(&g.dL_dscale[3 * gid + 2], d_scale.z);
-                        atomicAdd(&g.dL_dmean[3 * gid], d_mean.x), atomicAdd(&g.dL_dmean[3 * gid + 1], d_mean.y), atomicAdd(&g.dL_dmean[3 * gid + 2], d_mean.z);
-                        atomicAdd(&g.dL_drotation[4 * gid], d_rot0), atomicAdd(&g.dL_drotation[4 * gid + 1], d_rot1);
-                        atomicAdd(&g.dL_drotation[4 * gid + 2], d_rot2), atomicAdd(&g.dL_drotation[4 * gid + 3], d_rot3);
-                        atomicAdd(&g.dL_drgb[3 * gid], d_rgb.x), atomicAdd(&g.dL_drgb[3 * gid + 1], d_rgb.y), atomicAdd(&g.dL_drgb[3 * gid + 2], d_rgb.z);
+                        float *grow = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE;
+                        atomicAdd(grow + GC_OPA, d_opacity);
+                        atomicAdd(grow + GC_SCALE, d_scale.x), atomicAdd(grow + GC_SCALE + 1, d_scale.y), atomicAdd(grow + GC_SCALE + 2, d_scale.z);
+                        atomicAdd(grow + GC_MEAN, d_mean.x), atomicAdd(grow + GC_MEAN + 1, d_mean.y), atomicAdd(grow + GC_MEAN + 2, d_mean.z);
+                        atomicAdd(grow + GC_ROT, d_rot0), atomicAdd(grow + GC_ROT + 1, d_rot1), atomicAdd(grow + GC_ROT + 2, d_rot2), atomicAdd(grow + GC_ROT + 3, d_rot3);
+                        atomicAdd(grow + GC_RGB, d_rgb.x), atomicAdd(grow + GC_RGB + 1, d_rgb.y), atomicAdd(grow + GC_RGB + 2, d_rgb.z);
                         if (step == 0) {
-                            atomicAdd(&g.dL_dnormal[3 * gid], d_n.x), atomicAdd(&g.dL_dnormal[3 * gid + 1], d_n.y), atomicAdd(&g.dL_dnormal[3 * gid + 2], d_n.z);
-                            atomicAdd(&g.dL_df0[3 * gid], d_f0.x), atomicAdd(&g.dL_df0[3 * gid + 1], d_f0.y), atomicAdd(&g.dL_df0[3 * gid + 2], d_f0.z);
-                            atomicAdd(&g.dL_droughness[gid], d_rough);
+                            atomicAdd(grow + GC_NORMAL, d_n.x), atomicAdd(grow + GC_NORMAL + 1, d_n.y), atomicAdd(grow + GC_NORMAL + 2, d_n.z);
+                            atomicAdd(grow + GC_F0, d_f0.x), atomicAdd(grow + GC_F0 + 1, d_f0.y), atomicAdd(grow + GC_F0 + 2, d_f0.z);
+                            atomicAdd(grow + GC_ROUGH, d_rough);
                         }
-                        atomicAdd(&g.total_weight[gid], weight);
+                        atomicAdd(grow + GC_WEIGHT, weight);
                     }
                 }
             }
@@ -859,40 +851,68 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
 // Second half of the bucketed bounce backward: one workgroup per bucket sums the bucket's records in LDS (ds_add_f32) and
 // adds the totals to the gradient tensors with plain read-modify-writes (a gaussian belongs to exactly one bucket and
 // no other kernel touches the gradients concurrently - stream order).
+#define EGR_BUCKET_SLICE 2048u // records one workgroup sums; heavy buckets (scene centre) are split over blockIdx.y
 __global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
     constexpr int BG = 1 << EGR_BUCKET_SHIFT; // gaussians per bucket
-    __shared__ float acc[15][BG];
+    __shared__ float acc[BG * 17];            // [gaussian][15 components], row padded to 17 words
     const uint32_t bucket = blockIdx.x;
     const uint32_t count = min(v.gb_count[bucket], v.gb_cap);
-    if (count == 0) return;
-    __syncthreads();
-    if (threadIdx.x == 0) v.gb_count[bucket] = 0; // empty for the next step
-    for (int i = threadIdx.x; i < 15 * BG; i += 256) (&acc[0][0])[i] = 0.0f;
+    const uint32_t begin = blockIdx.y * EGR_BUCKET_SLICE;
+    if (begin >= count) return;
+    const uint32_t end = min(count, begin + EGR_BUCKET_SLICE);
+    const bool shared_bucket = count > EGR_BUCKET_SLICE; // several workgroups add into the same rows
+    for (int i = threadIdx.x; i < BG * 17; i += 256) acc[i] = 0.0f;
     __syncthreads();
     const float4 *src = v.gb_data + (size_t)bucket * v.gb_cap * 4;
-    for (uint32_t r = threadIdx.x; r < count; r += 256) {
+    for (uint32_t r = begin + threadIdx.x; r < end; r += 256) {
         const float4 a = src[4 * (size_t)r], b = src[4 * (size_t)r + 1], c = src[4 * (size_t)r + 2], d = src[4 * (size_t)r + 3];
-        const uint32_t l = f2u(a.x);
-        atomicAdd(&acc[0][l], a.y), atomicAdd(&acc[1][l], a.z), atomicAdd(&acc[2][l], a.w), atomicAdd(&acc[3][l], b.x);
-        atomicAdd(&acc[4][l], b.y), atomicAdd(&acc[5][l], b.z), atomicAdd(&acc[6][l], b.w);
-        atomicAdd(&acc[7][l], c.x), atomicAdd(&acc[8][l], c.y), atomicAdd(&acc[9][l], c.z), atomicAdd(&acc[10][l], c.w);
-        atomicAdd(&acc[11][l], d.x), atomicAdd(&acc[12][l], d.y), atomicAdd(&acc[13][l], d.z), atomicAdd(&acc[14][l], d.w);
+        float *dst = acc + 17 * f2u(a.x);
+        atomicAdd(dst + 0, a.y), atomicAdd(dst + 1, a.z), atomicAdd(dst + 2, a.w), atomicAdd(dst + 3, b.x);
+        atomicAdd(dst + 4, b.y), atomicAdd(dst + 5, b.z), atomicAdd(dst + 6, b.w);
+        atomicAdd(dst + 7, c.x), atomicAdd(dst + 8, c.y), atomicAdd(dst + 9, c.z), atomicAdd(dst + 10, c.w);
+        atomicAdd(dst + 11, d.x), atomicAdd(dst + 12, d.y), atomicAdd(dst + 13, d.z), atomicAdd(dst + 14, d.w);
     }
     __syncthreads();
-    const uint32_t pos = bucket * BG + threadIdx.x;
-    if (threadIdx.x < BG && pos < v.n) {
-        const uint32_t l = threadIdx.x;
-        if (acc[14][l] != 0.0f || acc[0][l] != 0.0f) {
-            const uint32_t gid = v.gid_of_pos[pos];
-            const egr_gaussians &g = v.g;
-            g.dL_dopacity[gid] += acc[0][l];
-            g.dL_dscale[3 * gid] += acc[1][l], g.dL_dscale[3 * gid + 1] += acc[2][l], g.dL_dscale[3 * gid + 2] += acc[3][l];
-            g.dL_dmean[3 * gid] += acc[4][l], g.dL_dmean[3 * gid + 1] += acc[5][l], g.dL_dmean[3 * gid + 2] += acc[6][l];
-            g.dL_drotation[4 * gid] += acc[7][l], g.dL_drotation[4 * gid + 1] += acc[8][l], g.dL_drotation[4 * gid + 2] += acc[9][l], g.dL_drotation[4 * gid + 3] += acc[10][l];
-            g.dL_drgb[3 * gid] += acc[11][l], g.dL_drgb[3 * gid + 1] += acc[12][l], g.dL_drgb[3 * gid + 2] += acc[13][l];
-            g.total_weight[gid] += acc[14][l];
-        }
+    // 16 consecutive threads write the first 64 B of one gradient row: coalesced, no scatter over the gradient tensors
+    for (int i = threadIdx.x; i < BG * 16; i += 256) {
+        const uint32_t l = (uint32_t)i >> 4, cidx = (uint32_t)i & 15u, pos = bucket * BG + l;
+        if (cidx >= 15u || pos >= v.n) continue;
+        const float x = acc[17 * l + cidx];
+        if (x == 0.0f) continue;
+        float *dst = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE + cidx;
+        if (shared_bucket) atomicAdd(dst, x);
+        else *dst += x;
     }
+}
+
+// Last backward kernel: one thread per gaussian id adds its gradient row (a 128-B line at its record position) to the
+// caller's gradient tensors - coalesced on the tensor side - and empties the row for the next launch.
+__global__ void __launch_bounds__(256) k_grad_gather(DeviceView v) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= v.n) return;
+    float4 *row = reinterpret_cast<float4 *>(v.grad_rows + (size_t)v.pos_of_gid[gid] * EGR_ROW_STRIDE);
+    float x[24];
+    uint32_t any = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const float4 r = row[q];
+        x[4 * q] = r.x, x[4 * q + 1] = r.y, x[4 * q + 2] = r.z, x[4 * q + 3] = r.w;
+        any |= (f2u(r.x) | f2u(r.y) | f2u(r.z) | f2u(r.w)) << 1; // ignore the sign bit: -0 is empty too
+    }
+    if (any == 0) return;
+#pragma unroll
+    for (int q = 0; q < 6; q++) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const egr_gaussians &g = v.g;
+    g.dL_dopacity[gid] += x[GC_OPA];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        g.dL_dscale[3 * gid + a] += x[GC_SCALE + a], g.dL_dmean[3 * gid + a] += x[GC_MEAN + a], g.dL_drgb[3 * gid + a] += x[GC_RGB + a];
+        g.dL_dnormal[3 * gid + a] += x[GC_NORMAL + a], g.dL_df0[3 * gid + a] += x[GC_F0 + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) g.dL_drotation[4 * gid + a] += x[GC_ROT + a];
+    g.dL_droughness[gid] += x[GC_ROUGH];
+    g.total_weight[gid] += x[GC_WEIGHT];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1052,7 +1072,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.num_tasks = egr_num_tasks_for_rank(c);
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
-    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.app = c->app;
+    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
@@ -1088,11 +1108,17 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
                 egr_stamp_begin(c, bn[step], s);
                 hipLaunchKernelGGL(k_backward, grid, block, 0, s, v, step);
                 egr_stamp_end(c, s);
-                if (step >= 1 && v.gb_data && nbuckets) { // reduce (and empty) the buckets after every bounce step
-                    egr_stamp_begin(c, step == 1 ? "backward_bucket_reduce1" : "backward_bucket_reduce2", s);
-                    hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets), dim3(256), 0, s, v);
+                if (step == 1 && v.gb_data && nbuckets) { // one reduce for both bounce steps (the counters were zeroed above)
+                    egr_stamp_begin(c, "backward_bucket_reduce", s);
+                    const uint32_t slices = (v.gb_cap + EGR_BUCKET_SLICE - 1u) / EGR_BUCKET_SLICE;
+                    hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(256), 0, s, v);
                     egr_stamp_end(c, s);
                 }
+            }
+            if (v.n) {
+                egr_stamp_begin(c, "backward_grad_gather", s);
+                hipLaunchKernelGGL(k_grad_gather, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
+                egr_stamp_end(c, s);
             }
         } else {
             egr_stamp_begin(c, "write_outputs", s);
