@@ -86,6 +86,9 @@ struct DeviceView { // everything a kernel needs, passed by value
     float4 *gb_data;       // [buckets][gb_cap][4] 64-B gradient records of the bounce-step backward
     uint32_t *gb_count;    // [buckets]
     uint32_t gb_cap;
+    uint32_t task_begin, task_count; // this strand's slice of the rank's task order (see egr_trace_launch)
+    uint32_t *queues;      // [strands][6 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
+    uint32_t num_strands;
     uint32_t group_lanes;  // lanes that walk the tree in lockstep on the non-packet path (power of two, 1..64)
 };
 
@@ -151,6 +154,12 @@ struct egr_context {
     float4 *gb_data = nullptr;
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
     int bucketed_backward = 1;
+    // strands: the rank's tiles are cut into `strands` slices whose kernel sequences run on separate HIP streams, so one
+    // slice's persistent-wave tail (few long tiles left) is filled by the other slice's next kernel
+    int strands = 2;
+    hipStream_t strand_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t *queues = nullptr;
     uint32_t cand_cap = 0, num_slots = 0;
     float4 *hit_arena = nullptr;
     uint32_t hit_blocks_cap = 0;

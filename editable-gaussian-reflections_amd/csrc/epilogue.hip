@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_step_epilogue(DeviceView v, int st
     const int lane = threadIdx.x;
     const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
     if (step > num_bounces) return;
-    for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
+    for (uint32_t task = v.task_begin + blockIdx.x; task < v.task_begin + v.task_count; task += gridDim.x) {
         const TaskGeom tg = task_geom(v, task, lane);
         if (!tg.inside) continue;
         StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
@@ -72,5 +72,5 @@ __global__ void __launch_bounds__(EGR_WAVE) k_step_epilogue(DeviceView v, int st
 } // namespace
 
 void egr_launch_step_epilogue(const DeviceView &v, int step, bool grads, hipStream_t s) {
-    hipLaunchKernelGGL(k_step_epilogue, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, step, grads ? 1 : 0);
+    hipLaunchKernelGGL(k_step_epilogue, dim3(std::max(1u, std::min(v.task_count, 65535u))), dim3(EGR_WAVE), 0, s, v, step, grads ? 1 : 0);
 }

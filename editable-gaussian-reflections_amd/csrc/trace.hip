@@ -173,7 +173,7 @@ __global__ void k_prologue(DeviceView v, int grads) {
     if (t < CW_RESET_END) v.control[t] = 0;
     if (t >= CW_DBG && t < CW_COUNT) v.control[t] = 0;
     if (t < 16) v.control[CW_DBG2 + t] = 0;
-    if (t < 48) v.control[CW_XQ + t] = 0;
+    for (uint32_t q = t; q < 48u * v.num_strands; q += blockDim.x) v.queues[q] = 0;
     if (t < 12) v.control[CW_DBG3 + t] = ((t & 3) < 2) ? 0xFFFFFFFFu : 0u;
     if (t == 0) {
         *v.meta.grads_enabled = grads ? 1 : 0;   // metadata.h:29
@@ -211,8 +211,11 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v) {
 // ---------------------------------------------------------------------------------------------------------
 template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(DeviceView v, int step) {
     const int lane = threadIdx.x;
-    float *__restrict__ keys = v.cand_keys + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
-    float2 *__restrict__ vals = v.cand_vals + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
+    // candidate scratch of this resident wave: every lane owns a CONTIGUOUS run of cand_cap entries ([lane][k]). Lanes append at
+    // their own pace, so a [k][lane] interleave never coalesces and every 4-B store dirties its own line (measured 4.4 KB
+    // written per ray); contiguous runs let the L2 merge 16 appends into one line.
+    float *__restrict__ keys = v.cand_keys + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
+    float2 *__restrict__ vals = v.cand_vals + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
     const uint4 *__restrict__ wnodes = v.wnodes;
     __shared__ uint32_t lstk[EGR_LSTK][EGR_WAVE]; // per-lane traversal stack (this workgroup is one wave)
     const float4 *__restrict__ app = v.app;
@@ -231,8 +234,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     uint32_t cur_q = blockIdx.x & 7u;
 
     for (;;) {
-        const uint32_t task = wave_next_task(v.control + CW_XQ + 8 * step, v.num_tasks, cur_q);
-        if (task >= v.num_tasks) break;
+        const uint32_t tq = wave_next_task(v.queues + 8 * step, v.task_count, cur_q);
+        if (tq == 0xFFFFFFFFu) break;
+        const uint32_t task = v.task_begin + tq;
         const TaskGeom tg = task_geom(v, task, lane);
         StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
         if (GRADS && lane == 0) v.task_last_block[(size_t)step * v.num_tasks + task] = 0xFFFFFFFFu; // nothing recorded yet
@@ -308,8 +312,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             float alpha = EGR_MAX_ALPHA * gaussval * a2.z;             // kernel.cu:14-16
             full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
             if (cnt < v.cand_cap) {
-                keys[(size_t)cnt * EGR_WAVE + lane] = t;
-                vals[(size_t)cnt * EGR_WAVE + lane] = make_float2(alpha, u2f(prim));
+                keys[cnt] = t;
+                vals[cnt] = make_float2(alpha, u2f(prim));
                 cnt++;
             } else {
                 overflow = true;
@@ -396,7 +400,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             // ---- per-lane walk: DFS with a per-lane stack (LDS [depth][lane], conflict-free; deeper entries spill to a
             // per-wave global column). Phase A queues the leaves whose box the lane's segment overlaps, phase B evaluates
             // them (decoupled so that the wave does not rendezvous at every leaf).
-            uint32_t *__restrict__ queue = v.cand_queue + (size_t)blockIdx.x * v.cand_cap * EGR_WAVE;
+            uint32_t *__restrict__ queue = v.cand_queue + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
             uint32_t *__restrict__ gstk = v.stack_spill + (size_t)blockIdx.x * EGR_GSTK * EGR_WAVE;
             uint32_t sp = 0;
             auto push = [&](uint32_t x) {
@@ -405,6 +409,10 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 else overflow = true; // > 256 pending subtrees: cannot happen for trees the builder produces
             };
             if (ray_ok) push(0u);
+            // leaf ids are staged four at a time in registers: one 16-B store / load per four queue entries (every store is
+            // its own L2 write request on the write-through L1, and L2 requests per ray are what bounds this kernel)
+            uint4 pend = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t np = 0;
 #ifdef EGR_TRAVERSAL_STATS
             unsigned long long tA = 0, tB = 0;
 #endif
@@ -412,7 +420,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #ifdef EGR_TRAVERSAL_STATS
                 const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
 #endif
-                while (sp > 0 && nq + EGR_WIDTH <= v.cand_cap) { // phase A
+                while (sp > 0 && nq + 4u + EGR_WIDTH <= v.cand_cap) { // phase A
                     sp--;
                     const uint32_t w = sp < EGR_LSTK ? lstk[sp][lane] : gstk[(size_t)(sp - EGR_LSTK) * EGR_WAVE + lane];
                     const uint4 *__restrict__ nd = wnodes + (size_t)w * EGR_WIDTH;
@@ -427,17 +435,24 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                     for (int k = EGR_WIDTH - 1; k >= 0; k--) { // reverse: slot 0 is popped first
                         if (sl[k].w == EGR_EMPTY_SLOT) continue;
                         if (!qslab_hit(sl[k], invq, ncq, seg_lo, seg_hi)) continue;
-                        if (sl[k].w & EGR_LEAF_FLAG) queue[(size_t)nq * EGR_WAVE + lane] = sl[k].w & ~EGR_LEAF_FLAG, nq++;
-                        else push(sl[k].w);
+                        if (sl[k].w & EGR_LEAF_FLAG) {
+                            const uint32_t id = sl[k].w & ~EGR_LEAF_FLAG;
+                            pend.x = np == 0u ? id : pend.x, pend.y = np == 1u ? id : pend.y, pend.z = np == 2u ? id : pend.z, pend.w = np == 3u ? id : pend.w;
+                            if (++np == 4u) *reinterpret_cast<uint4 *>(queue + nq) = pend, nq += 4u, np = 0u;
+                        } else
+                            push(sl[k].w);
                     }
                 }
+                if (np) *reinterpret_cast<uint4 *>(queue + nq) = pend, nq += np, np = 0u; // partial last group
 #ifdef EGR_TRAVERSAL_STATS
                 st_leafhits += nq;
                 const unsigned long long ta1 = __builtin_amdgcn_s_memtime();
                 tA += ta1 - ta0;
 #endif
+                uint4 grp = make_uint4(0u, 0u, 0u, 0u);
                 for (uint32_t q = 0; q < nq; q++) { // phase B
-                    const uint32_t p = queue[(size_t)q * EGR_WAVE + lane];
+                    if ((q & 3u) == 0u) grp = *reinterpret_cast<const uint4 *>(queue + q);
+                    const uint32_t j = q & 3u, p = j == 0u ? grp.x : j == 1u ? grp.y : j == 2u ? grp.z : grp.w;
 #ifdef EGR_TRAVERSAL_STATS
                     st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
 #endif
@@ -501,16 +516,14 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                             }
                         }
                     };
-                    // coalesced 256-B row loads, 8 in flight before any is consumed (the scan is latency-bound otherwise)
+                    // two 16-B loads per 8 keys (cand_cap is a multiple of 8, so runs are 32-B aligned), in flight together
                     uint32_t k = 0;
                     for (; k + 8 <= cnt; k += 8) {
-                        float tk[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) tk[j] = keys[(size_t)(k + j) * EGR_WAVE + lane];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) consider(tk[j], k + j);
+                        const float4 ka = *reinterpret_cast<const float4 *>(keys + k), kb = *reinterpret_cast<const float4 *>(keys + k + 4);
+                        consider(ka.x, k), consider(ka.y, k + 1), consider(ka.z, k + 2), consider(ka.w, k + 3);
+                        consider(kb.x, k + 4), consider(kb.y, k + 5), consider(kb.z, k + 6), consider(kb.w, k + 7);
                     }
-                    for (; k < cnt; k++) consider(keys[(size_t)k * EGR_WAVE + lane], k);
+                    for (; k < cnt; k++) consider(keys[k], k);
                     if (ki[0] == 0xFFFFFFFFu || !(kt[0] < far_plane)) running = false; // :81, :91-93
                 }
                 if (__ballot(running) == 0ull) break;
@@ -533,7 +546,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         const float best = kt[j];
                         t_prev = best;
                         k_prev = ki[j];
-                        float2 av = vals[(size_t)ki[j] * EGR_WAVE + lane];
+                        float2 av = vals[ki[j]];
                         float alpha = av.x;
                         uint32_t pos = f2u(av.y); // record index (sorted position)
                         float4 a0 = app[2 * pos], a1 = app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
@@ -663,8 +676,9 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
     const bool bucketed = step > 0 && v.gb_data != nullptr;
 
     for (;;) {
-        const uint32_t task = wave_next_task(v.control + CW_XQ + 8 * (3 + step), v.num_tasks, cur_q);
-        if (task >= v.num_tasks) break;
+        const uint32_t tq = wave_next_task(v.queues + 8 * (3 + step), v.task_count, cur_q);
+        if (tq == 0xFFFFFFFFu) break;
+        const uint32_t task = v.task_begin + tq;
         uint32_t blk = v.task_last_block[(size_t)step * v.num_tasks + task];
         if (blk == 0xFFFFFFFFu) continue;
         const TaskGeom tg = task_geom(v, task, lane);
@@ -923,7 +937,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_finish(DeviceView v) {
     const bool accumulate = *v.cfg.accumulate_samples != 0;
     const float cnt = accumulate ? (float)(*v.fb.accumulated_sample_count + 1) : 1.0f;
     const size_t P = v.num_pixels;
-    for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
+    for (uint32_t task = v.task_begin + blockIdx.x; task < v.task_begin + v.task_count; task += gridDim.x) {
         const TaskGeom tg = task_geom(v, task, lane);
         if (!tg.inside) continue;
         StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
@@ -1004,7 +1018,14 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control);
+    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues);
+    for (int i = 0; i < 4; i++) {
+        if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        c->strand_stream[i] = nullptr, c->ev_join[i] = nullptr;
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    c->ev_fork = nullptr;
     if (c->control_host) (void)hipHostFree(c->control_host);
     c->control_host = nullptr;
 }
@@ -1023,12 +1044,13 @@ void egr_trace_alloc(egr_context *c) {
     c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
     // forward budget: the reference's ppll_forward_size entries x 36 B, spent on (key 4 B + value 8 B) x 64 lanes x cap per slot
     double fwd_bytes = (double)c->fwd_capacity * 36.0;
-    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * EGR_WAVE * 16.0)); // key 4 + value 8 + queue 4 bytes
-    c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384);
-    EGR_HIP(hipMalloc((void **)&c->cand_keys, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
-    EGR_HIP(hipMalloc((void **)&c->cand_vals, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
-    EGR_HIP(hipMalloc((void **)&c->cand_queue, (size_t)c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
-    EGR_HIP(hipMalloc((void **)&c->stack_spill, (size_t)c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
+    const size_t S = (size_t)c->strands; // every strand owns a full set of resident-wave scratch slots
+    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * (double)S * EGR_WAVE * 16.0)); // key 4 + value 8 + queue 4 bytes
+    c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384) & ~7u;
+    EGR_HIP(hipMalloc((void **)&c->cand_keys, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
+    EGR_HIP(hipMalloc((void **)&c->cand_vals, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
+    EGR_HIP(hipMalloc((void **)&c->cand_queue, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->stack_spill, S * c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
     double bwd_bytes = (double)c->bwd_capacity * 36.0;
     if (c->bucketed_backward) bwd_bytes *= 0.25; // the rest holds the gradient buckets
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
@@ -1041,6 +1063,15 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->control, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipMemset(c->control, 0, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipHostMalloc((void **)&c->control_host, CW_COUNT * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->queues, 48 * S * sizeof(uint32_t)));
+    EGR_HIP(hipMemset(c->queues, 0, 48 * S * sizeof(uint32_t)));
+    if (c->strands > 1) {
+        EGR_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < c->strands; i++) {
+            EGR_HIP(hipStreamCreateWithFlags(&c->strand_stream[i], hipStreamNonBlocking));
+            EGR_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
+    }
     EGR_HIP(hipMalloc((void **)&c->task_macro, std::max<size_t>(c->num_tasks_total / 4, 1) * sizeof(uint32_t)));
     egr_build_task_order(c);
 }
@@ -1070,6 +1101,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.num_nodes = c->num_wide;
     v.rank = c->rank, v.world = c->world;
     v.num_tasks = egr_num_tasks_for_rank(c);
+    v.task_begin = 0, v.task_count = v.num_tasks, v.queues = c->queues, v.num_strands = (uint32_t)c->strands;
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
@@ -1084,7 +1116,7 @@ DeviceView egr_make_view(const egr_context *c) {
 
 void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
     DeviceView v = egr_make_view(c);
-    const dim3 grid(std::max(1u, std::min(c->num_slots, std::max(1u, v.num_tasks)))), block(EGR_WAVE);
+    const dim3 block(EGR_WAVE);
     egr_stamp_begin(c, "prologue+live", s);
     hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
     EGR_HIP(hipMemsetAsync(c->stats.num_accumulated_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s)); // stats.h:25-28
@@ -1093,37 +1125,62 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
     egr_stamp_end(c, s);
     static const char *fn[3] = {"forward_step0", "forward_step1", "forward_step2"};
     static const char *bn[3] = {"backward_step0", "backward_step1", "backward_step2"};
+    const uint32_t nbuckets = (v.n + (1u << EGR_BUCKET_SHIFT) - 1u) >> EGR_BUCKET_SHIFT;
     if (v.num_tasks) {
-        for (int step = 0; step < EGR_NSTEPS; step++) {
-            egr_stamp_begin(c, fn[step], s);
-            if (grads) hipLaunchKernelGGL(k_forward<true>, grid, block, 0, s, v, step);
-            else hipLaunchKernelGGL(k_forward<false>, grid, block, 0, s, v, step);
-            egr_launch_step_epilogue(v, step, grads, s);
-            egr_stamp_end(c, s);
+        if (grads && v.gb_data && nbuckets) EGR_HIP(hipMemsetAsync(v.gb_count, 0, nbuckets * sizeof(uint32_t), s));
+        // Strands: slices of the task order (whole macro tiles), each with its own queues and scratch slots, each running the
+        // step kernels in order on its own stream. Tiles only depend on their own earlier steps, so strands never synchronise
+        // with each other until the join; while one strand's kernel drains its last long tiles the next kernel of another
+        // strand takes the freed wave slots.
+        const int S = (v.num_tasks >= 8u * (uint32_t)c->strands) ? c->strands : 1;
+        if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
+        for (int st = 0; st < S; st++) {
+            hipStream_t ls = S > 1 ? c->strand_stream[st] : s;
+            if (S > 1) EGR_HIP(hipStreamWaitEvent(ls, c->ev_fork, 0));
+            DeviceView w = v;
+            const uint32_t groups = v.num_tasks / 4u; // tasks come in groups of 4 (one macro tile)
+            w.task_begin = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)st) / (uint64_t)S);
+            w.task_count = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)(st + 1)) / (uint64_t)S) - w.task_begin;
+            w.queues = c->queues + 48 * st;
+            const size_t slot0 = (size_t)st * c->num_slots;
+            w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE, w.cand_queue += slot0 * c->cand_cap * EGR_WAVE;
+            w.stack_spill += slot0 * EGR_GSTK * EGR_WAVE;
+            const dim3 sgrid(std::max(1u, std::min(c->num_slots, w.task_count)));
+            for (int step = 0; step < EGR_NSTEPS; step++) {
+                egr_stamp_begin(c, fn[step], ls);
+                if (grads) hipLaunchKernelGGL(k_forward<true>, sgrid, block, 0, ls, w, step);
+                else hipLaunchKernelGGL(k_forward<false>, sgrid, block, 0, ls, w, step);
+                egr_launch_step_epilogue(w, step, grads, ls);
+                egr_stamp_end(c, ls);
+            }
+            if (grads) {
+                for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
+                    egr_stamp_begin(c, bn[step], ls);
+                    hipLaunchKernelGGL(k_backward, sgrid, block, 0, ls, w, step);
+                    egr_stamp_end(c, ls);
+                }
+            } else {
+                egr_stamp_begin(c, "write_outputs", ls);
+                hipLaunchKernelGGL(k_finish, dim3(std::max(1u, std::min(w.task_count, 65535u))), block, 0, ls, w);
+                egr_stamp_end(c, ls);
+            }
+            if (S > 1) {
+                EGR_HIP(hipEventRecord(c->ev_join[st], ls));
+                EGR_HIP(hipStreamWaitEvent(s, c->ev_join[st], 0));
+            }
         }
         if (grads) {
-            const uint32_t nbuckets = (v.n + (1u << EGR_BUCKET_SHIFT) - 1u) >> EGR_BUCKET_SHIFT;
-            if (v.gb_data && nbuckets) EGR_HIP(hipMemsetAsync(v.gb_count, 0, nbuckets * sizeof(uint32_t), s));
-            for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
-                egr_stamp_begin(c, bn[step], s);
-                hipLaunchKernelGGL(k_backward, grid, block, 0, s, v, step);
+            if (v.gb_data && nbuckets) { // one reduce for both bounce steps of all strands
+                egr_stamp_begin(c, "backward_bucket_reduce", s);
+                const uint32_t slices = (v.gb_cap + EGR_BUCKET_SLICE - 1u) / EGR_BUCKET_SLICE;
+                hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(256), 0, s, v);
                 egr_stamp_end(c, s);
-                if (step == 1 && v.gb_data && nbuckets) { // one reduce for both bounce steps (the counters were zeroed above)
-                    egr_stamp_begin(c, "backward_bucket_reduce", s);
-                    const uint32_t slices = (v.gb_cap + EGR_BUCKET_SLICE - 1u) / EGR_BUCKET_SLICE;
-                    hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(256), 0, s, v);
-                    egr_stamp_end(c, s);
-                }
             }
             if (v.n) {
                 egr_stamp_begin(c, "backward_grad_gather", s);
                 hipLaunchKernelGGL(k_grad_gather, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
                 egr_stamp_end(c, s);
             }
-        } else {
-            egr_stamp_begin(c, "write_outputs", s);
-            hipLaunchKernelGGL(k_finish, dim3(std::min(v.num_tasks, 65535u)), block, 0, s, v);
-            egr_stamp_end(c, s);
         }
     }
     hipLaunchKernelGGL(k_epilogue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);

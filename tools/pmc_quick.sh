@@ -3,7 +3,8 @@
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 for C in "$@"; do
-  timeout 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/$TAG/$C -o p -- python tools/pmc_run.py > gpurun_out/$TAG.$C.log 2>&1
+  C=${C//,/ }
+  timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/$TAG/${C// /_} -o p -- python tools/pmc_run.py > "gpurun_out/$TAG.${C// /_}.log" 2>&1
 done
 python - <<PY
 import csv,glob,collections

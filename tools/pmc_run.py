@@ -2,7 +2,7 @@
 import importlib, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic"); ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
-W, H, N = 1920, 1080, 1_000_000
+W, H, N = int(os.environ.get("PMC_W", 1920)), int(os.environ.get("PMC_H", 1080)), 1_000_000
 g = syn.make_scene(N, "trained", seed=0); cam = syn.default_camera(); tg = syn.make_targets(W, H)
 pc = ren.GaussianParams(g)
 rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000)
