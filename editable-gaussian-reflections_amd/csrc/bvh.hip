@@ -138,18 +138,38 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) { // 21 bits -> every t
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
-__global__ void __launch_bounds__(BS) k_morton(uint32_t n, const float *__restrict__ mean, BvhFrame fr,
+// Sort key of a gaussian: Morton code of its mean, optionally EXTENDED with the size of its box (Vinkler, Bittner, Havran 2017:
+// "Extended Morton codes for high performance bounding volume hierarchy construction"): the key interleaves quantised
+// x, y, z and size bits following `pattern` (period `period`, dimension 3 = size). A gaussian much larger than the cell
+// it sits in is then split off into its own subtree at the level where the cell size reaches its own size, instead of
+// inflating the boxes of all the small gaussians that share its Morton cell.
+struct MortonPattern {
+    uint8_t dim[8];
+    uint32_t period;
+};
+__global__ void __launch_bounds__(BS) k_morton(uint32_t n, const float *__restrict__ mean, const float *__restrict__ aabb, BvhFrame fr, MortonPattern pat,
                                                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * BS + threadIdx.x;
     if (i >= n) return;
-    uint64_t key = 0;
     const float fo[3] = {fr.ox, fr.oy, fr.oz}, fs[3] = {fr.sx, fr.sy, fr.sz};
+    uint32_t q[4]; // 21-bit fixed point in [0,1): x, y, z, size
+    float size = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         float v = mean[3 * i + a];
         float u = isfinite(v) ? (v - fo[a]) * fs[a] * (1.0f / 65536.0f) : 0.0f; // [0,1) inside the frame
-        uint32_t q = (uint32_t)fminf(fmaxf(u * 2097152.0f, 0.0f), 2097151.0f);
-        key |= spread21(q) << (2 - a);
+        q[a] = (uint32_t)fminf(fmaxf(u * 2097152.0f, 0.0f), 2097151.0f);
+        const float ext = (aabb[6 * i + 3 + a] - aabb[6 * i + a]) * fs[a] * (1.0f / 65536.0f); // box extent / frame extent
+        size = fmaxf(size, (ext >= 0.0f && ext <= 1.0f) ? ext : 0.0f);                          // unusable (empty) boxes: 0
+    }
+    q[3] = (uint32_t)fminf(size * 2097152.0f, 2097151.0f);
+    uint64_t key = 0;
+    int used[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 63; b++) {
+        const int d = pat.dim[b % pat.period];
+        const uint32_t bit = used[d] < 21 ? (q[d] >> (20 - used[d])) & 1u : 0u;
+        used[d]++;
+        key = (key << 1) | bit;
     }
     keys[i] = key;
     vals[i] = i;
@@ -382,7 +402,16 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->frame.ox = lo[0], c->frame.oy = lo[1], c->frame.oz = lo[2];
         c->frame.sx = 65530.0f / (hi[0] - lo[0]), c->frame.sy = 65530.0f / (hi[1] - lo[1]), c->frame.sz = 65530.0f / (hi[2] - lo[2]);
     }
-    hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(BS), 0, s, n, c->g.mean, c->frame, c->keys_in, c->vals_in);
+    MortonPattern pat{{0, 1, 2, 0, 1, 2, 0, 0}, 3u};
+    if (c->morton_size_period > 0) { // x y z (repeated `morton_size_period` times) then one size bit
+        pat.period = 0;
+        const int reps = std::min(c->morton_size_period, 2);
+        for (int r = 0; r < reps; r++) pat.dim[pat.period++] = 0, pat.dim[pat.period++] = 1, pat.dim[pat.period++] = 2;
+        pat.dim[pat.period++] = 3;
+    } else if (c->morton_size_period < 0) { // size bit first: s x y z
+        pat.dim[0] = 3, pat.dim[1] = 0, pat.dim[2] = 1, pat.dim[3] = 2, pat.period = 4;
+    }
+    hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(BS), 0, s, n, c->g.mean, c->aabb, c->frame, pat, c->keys_in, c->vals_in);
     size_t bytes = c->sort_tmp_bytes;
     EGR_HIP(rocprim::radix_sort_pairs(c->sort_tmp, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)n, 0, 63, s));
     hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(n)), dim3(BS), 0, s, n, c->vals_out, c->pos_of_gid);

@@ -154,6 +154,7 @@ struct egr_context {
     float4 *gb_data = nullptr;
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
     int bucketed_backward = 1;
+    int morton_size_period = 0; // 0: plain Morton order; k > 0: one size bit after every k xyz triples; < 0: size bit first (s x y z)
     // strands: the rank's tiles are cut into `strands` slices whose kernel sequences run on separate HIP streams, so one
     // slice's persistent-wave tail (few long tiles left) is filled by the other slice's next kernel
     int strands = 2;

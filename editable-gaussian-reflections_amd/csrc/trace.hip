@@ -422,7 +422,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #endif
                 while (sp > 0 && nq + 4u + EGR_WIDTH <= v.cand_cap) { // phase A
                     sp--;
-                    const uint32_t w = sp < EGR_LSTK ? lstk[sp][lane] : gstk[(size_t)(sp - EGR_LSTK) * EGR_WAVE + lane];
+                    uint32_t w = lstk[min(sp, (uint32_t)EGR_LSTK - 1u)][lane]; // always an LDS read (a select of the two addresses compiles to a FLAT load)
+                    if (sp >= EGR_LSTK) w = *reinterpret_cast<const volatile uint32_t *>(gstk + (size_t)(sp - EGR_LSTK) * EGR_WAVE + lane); // rare spill; volatile keeps it a separate global load
                     const uint4 *__restrict__ nd = wnodes + (size_t)w * EGR_WIDTH;
                     uint4 sl[EGR_WIDTH];
 #pragma unroll
