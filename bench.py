@@ -31,8 +31,8 @@ sys.path.insert(0, ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=50)  # ~1.5 s of load: the core clock needs about that long to ramp (measured)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--gaussians", type=int, default=1_000_000)
@@ -40,7 +40,8 @@ def parse():
     p.add_argument("--bounces", type=int, default=2)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="480x270")
-    p.add_argument("--profile-steps", type=int, default=5, help="extra untimed launches with per-kernel HIP events")
+    p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
+    p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default, 2); the per-kernel profile pass always uses 1")
     p.add_argument("--forward-only", action="store_true", help="config B: no-grad render instead of a training iteration")
     return p.parse_args()
 
@@ -90,6 +91,8 @@ def main():
     rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000, rank=rank, world_size=world)
     m = rt.cuda_module
     m.get_config().num_bounces.fill_(a.bounces)
+    if a.strands > 0:
+        m.set_strands(a.strands)
     images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()}
     camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **images)
 
@@ -166,6 +169,10 @@ def main():
     roof = None
     kern = {}
     acc = {}
+    # the profile pass runs the kernels one at a time (strands = 1): a kernel's duration is then its exclusive time on the GPU
+    m.set_strands(1)
+    for _ in range(min(a.warmup, 30) if a.profile_steps > 0 else 0):  # the CPU baseline above left the GPU idle: ramp the clocks again
+        one_step()
     m.enable_timing(rank == 0)
     for _ in range(a.profile_steps):  # every rank runs these steps (they contain the all-reduce); rank 0 reads the stamps
         one_step()
@@ -178,7 +185,7 @@ def main():
     m.enable_timing(False)
     barrier()
     if rank == 0 and a.profile_steps > 0:
-        kern = {k: float(np.mean(v)) for k, v in acc.items() if v and v[0] >= 0}
+        kern = {k: float(np.median(v)) for k, v in acc.items() if v and v[0] >= 0}
         cc = m.get_counters()
         rays, cand, comp = cc[0:3], list(cc[3:6]), cc[6:9]
         pixels_rank = rays[0]
@@ -215,6 +222,7 @@ def main():
                 "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
                 "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
                 "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
+                "strands_timed_region": a.strands if a.strands > 0 else int(os.environ.get("EGR_STRANDS", 2)), "strands_profile_pass": 1,
                 "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
 
     if rank == 0:

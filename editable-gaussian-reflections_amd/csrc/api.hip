@@ -124,6 +124,12 @@ int egr_set_partition(egr_context *c, int rank, int world) {
     });
 }
 
+int egr_set_strands(egr_context *c, int strands) {
+    if (!c || strands < 1 || strands > c->strands) return 1;
+    c->strands_active = strands;
+    return 0;
+}
+
 static int require_ready(egr_context *c, bool need_bvh) {
     if (!c->bound || !c->have_gaussians) {
         c->last_error = "libegr_hip: egr_bind / egr_set_gaussians must be called first";

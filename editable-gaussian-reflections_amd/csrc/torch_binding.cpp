@@ -374,6 +374,7 @@ struct Raytracer : torch::CustomClassHolder {
     }
     // ---- additions (not in the reference) ----
     void set_partition(int64_t rank, int64_t world) { check(egr_set_partition(ctx, (int)rank, (int)world), "set_partition"); }
+    void set_strands(int64_t n) { TORCH_CHECK(egr_set_strands(ctx, (int)n) == 0, "set_strands: 1..EGR_STRANDS (value at creation) expected"); }
     std::vector<int64_t> get_counters() { // synchronises
         egr_counters c{};
         check(egr_get_counters(ctx, &c, current_stream()), "get_counters");
@@ -455,6 +456,7 @@ struct Raytracer : torch::CustomClassHolder {
                  })
             // additions for multi-GPU tile partitioning, measurement and tests
             .def("set_partition", &Raytracer::set_partition)
+            .def("set_strands", &Raytracer::set_strands)
             .def("get_counters", &Raytracer::get_counters)
             .def("reset_lifetime_counters", &Raytracer::reset_lifetime_counters)
             .def("enable_timing", &Raytracer::enable_timing)

@@ -1133,7 +1133,8 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
         // step kernels in order on its own stream. Tiles only depend on their own earlier steps, so strands never synchronise
         // with each other until the join; while one strand's kernel drains its last long tiles the next kernel of another
         // strand takes the freed wave slots.
-        const int S = (v.num_tasks >= 8u * (uint32_t)c->strands) ? c->strands : 1;
+        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : c->strands;
+        const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
         if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
         for (int st = 0; st < S; st++) {
             hipStream_t ls = S > 1 ? c->strand_stream[st] : s;

@@ -147,6 +147,12 @@ int egr_denoise(egr_context *ctx, void *hip_stream);
  * macro tiles with (tile_index % world_size) == rank; default rank 0 of 1 = whole image. */
 int egr_set_partition(egr_context *ctx, int rank, int world_size);
 
+/* Strands (not in the reference): egr_raytrace cuts this context's tiles into `strands` slices and runs their step kernels on
+ * separate internal HIP streams (forked from / joined to the caller's stream), so that one slice's persistent-wave tail is
+ * filled by another slice's next kernel. 1 = everything on the caller's stream (per-kernel timings are then exclusive).
+ * Accepts 1..(value at creation: env EGR_STRANDS, default 2); returns 1 otherwise. */
+int egr_set_strands(egr_context *ctx, int strands);
+
 /* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace. */
 int egr_get_counters(egr_context *ctx, egr_counters *out, void *hip_stream);
 int egr_reset_lifetime_counters(egr_context *ctx, void *hip_stream);

@@ -384,6 +384,36 @@ def test_tile_partition_sums_to_full_image(ren, orc, syn):
         assert np.abs(s - gfull[k]).max() / (np.abs(gfull[k]).max() + 1e-30) < 1e-3, k
 
 
+def test_strands_do_not_change_results(ren, orc, syn):
+    """The image slices traced on separate HIP streams (egr_set_strands) are independent: the images are bit-identical
+    with 1 or 2 strands, the gradients agree to float-atomic reordering."""
+    W, H = 96, 64
+    g = syn.make_scene(3000, "trained", seed=9)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    rt, _ = make_pair(ren, orc, g, cam, W, H)
+    m = rt.cuda_module
+    res = {}
+    for s in (1, 2):
+        m.set_strands(s)
+        m.get_metadata().total_num_calls.zero_()  # same jitter / GGX random stream for both launches
+        with torch.no_grad():
+            rt(cam_obj(ren, cam))
+        img = hip_outputs(rt)
+        m.get_metadata().total_num_calls.zero_()
+        run_grad(ren, rt, cam_obj(ren, cam, tg))
+        res[s] = (img, hip_grads(rt), m.get_counters()[:9])
+    for k in OUT_KEYS:
+        assert np.array_equal(res[1][0][k], res[2][0][k]), k
+    assert list(res[1][2]) == list(res[2][2])
+    for k in GRAD_KEYS:
+        assert np.abs(res[1][1][k] - res[2][1][k]).max() / (np.abs(res[1][1][k]).max() + 1e-30) < 1e-4, k
+    with pytest.raises(RuntimeError):
+        m.set_strands(0)
+    with pytest.raises(RuntimeError):
+        m.set_strands(99)
+
+
 # ------------------------------------------------------------------------------------------------ full size
 def test_full_size_properties_1080p_1M(ren, orc, syn):
     """BASELINE config C (1080p, 1M Gaussians): size-independent properties instead of a full oracle run."""
