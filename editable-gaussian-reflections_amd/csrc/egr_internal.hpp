@@ -89,6 +89,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t task_begin, task_count; // this strand's slice of the rank's task order (see egr_trace_launch)
     uint32_t *queues;      // [strands][6 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
+    int group_walk;        // 1: incoherent tiles walk with 8 lanes per ray (see k_forward), 0: one lane per ray
     uint32_t group_lanes;  // lanes that walk the tree in lockstep on the non-packet path (power of two, 1..64)
 };
 
@@ -154,6 +155,7 @@ struct egr_context {
     float4 *gb_data = nullptr;
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
     int bucketed_backward = 1;
+    int group_walk = 1;
     int morton_size_period = 0; // 0: plain Morton order; k > 0: one size bit after every k xyz triples; < 0: size bit first (s x y z)
     // strands: the rank's tiles are cut into `strands` slices whose kernel sequences run on separate HIP streams, so one
     // slice's persistent-wave tail (few long tiles left) is filled by the other slice's next kernel

@@ -217,7 +217,12 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     float *__restrict__ keys = v.cand_keys + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
     float2 *__restrict__ vals = v.cand_vals + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
     const uint4 *__restrict__ wnodes = v.wnodes;
-    __shared__ uint32_t lstk[EGR_LSTK][EGR_WAVE]; // per-lane traversal stack (this workgroup is one wave)
+    __shared__ uint32_t lstk[EGR_LSTK][EGR_WAVE]; // per-ray traversal stack (this workgroup is one wave)
+    __shared__ float rayt[6][EGR_WAVE];           // group walk: every ray's origin / direction, readable by its lane group
+    __shared__ uint32_t gq[EGR_WAVE];             // group walk: leaves queued per ray (0 = nothing to evaluate)
+    __shared__ uint32_t gsp[EGR_WAVE];            // group walk: stack height of a ray whose walk is not finished (0 = done)
+    __shared__ uint32_t gcnt[EGR_WAVE], gtrav[EGR_WAVE]; // group walk: accepted / counted candidates per ray
+    __shared__ float gT[EGR_WAVE];                // group walk: total transmittance per ray
     const float4 *__restrict__ app = v.app;
     const uint32_t END = v.num_nodes;
 
@@ -271,6 +276,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         // box the segment overlaps; phase B evaluates the queue. The queue lives in the lane's key column
         // (ids are overwritten by keys, write index <= read index).
         const bool ray_ok = active && finite3(ro) && finite3(rd); // NaN rays (ggx_brdf.h:163) hit nothing
+        const unsigned long long act_mask = __ballot(ray_ok);
         // the ray in the quantisation frame of the tree: cell = (x - o) * s + 2, same t parametrisation.
         // slab plane distance t = (cell - oq) / (d * s) is evaluated as fma(cell, invq, -oq * invq).
         const f3 invq = mk3(1.0f / (rd.x * v.frame.sx), 1.0f / (rd.y * v.frame.sy), 1.0f / (rd.z * v.frame.sz));
@@ -287,29 +293,38 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         float seg_lo, seg_hi;
         // R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record.
         // `prim` is the gaussian's SORTED POSITION (record index), not its id.
-        auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src) {
-            const f3 lo = mk3(w0.x * ro.x + w0.y * ro.y + w0.z * ro.z + w0.w, w1.x * ro.x + w1.y * ro.y + w1.z * ro.z + w1.w,
-                              w2.x * ro.x + w2.y * ro.y + w2.z * ro.z + w2.w);
-            const f3 ld = mk3(w0.x * rd.x + w0.y * rd.y + w0.z * rd.z, w1.x * rd.x + w1.y * rd.y + w1.z * rd.z,
-                              w2.x * rd.x + w2.y * rd.y + w2.z * rd.z);
-            if (!hits_unit_cube(lo, ld, near_plane, far_plane)) return;
+        // returns 0: not counted, 1: counted (reached the reference's intersection program), 2: accepted (t, alpha valid)
+        auto test_candidate = [&](const f3 &o, const f3 &d, uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src, float &t,
+                                  float &alpha) -> int {
+            const f3 lo = mk3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
+                              w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
+            const f3 ld = mk3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z,
+                              w2.x * d.x + w2.y * d.y + w2.z * d.z);
+            if (!hits_unit_cube(lo, ld, near_plane, far_plane)) return 0;
             f3 dhat, u;
-            float t;
             closest_point(lo, ld, dhat, t, u);              // :41-45
             // each candidate is owned by exactly one of the three walked segments (see below): counted / accepted once
-            if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return;
-            traversed++;                                    // shaders.cu:33 (evaluations that reached the intersection program)
-            if (dot(lo, ld) > 0.0f) return;                 // :36
-            if (dot(u, u) > 1.0f) return;                   // :48-51
+            if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return 0;
+            // counted here: shaders.cu:33 (evaluations that reached the intersection program)
+            if (dot(lo, ld) > 0.0f) return 1;               // :36
+            if (dot(u, u) > 1.0f) return 1;                 // :48-51
             if (step != 0 && t < backfacing_max_dist) {     // :54-61 (world normal . object dir)
                 const float4 n0 = app[2 * prim], n1 = app[2 * prim + 1]; // raw normal, record order (k_live)
                 f3 gn = mk3(n0.w, n1.x, n1.y);
-                if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) return;
+                if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) return 1;
             }
             const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
             f3 x = u * a2.w;                                          // :64
             float gaussval = eval_gaussian_sq(dot(x, x), exp_power);   // :65
-            float alpha = EGR_MAX_ALPHA * gaussval * a2.z;             // kernel.cu:14-16
+            alpha = EGR_MAX_ALPHA * gaussval * a2.z;                   // kernel.cu:14-16
+            return 2;
+        };
+        auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src) {
+            float t = 0.0f, alpha = 0.0f;
+            const int r = test_candidate(ro, rd, prim, w0, w1, w2, a2src, t, alpha);
+            if (r == 0) return;
+            traversed++;
+            if (r == 1) return;
             full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
             if (cnt < v.cand_cap) {
                 keys[cnt] = t;
@@ -348,6 +363,11 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         // [tmin,tmax] as long as the cube overlaps the segment (quirk Q1): those are exactly the hits found by walking
         // [0,tmin) and (tmax,inf) and keeping the ones whose cube still overlaps [tmin,tmax] (the cube test below always
         // uses the launch's near/far planes). Three disjoint ownership ranges -> every accepted candidate counted once.
+        const bool group_walk = !packet && v.group_walk != 0;
+        if (group_walk) { // publish the rays; per-ray results accumulate in LDS over the three segments
+            rayt[0][lane] = ro.x, rayt[1][lane] = ro.y, rayt[2][lane] = ro.z, rayt[3][lane] = rd.x, rayt[4][lane] = rd.y, rayt[5][lane] = rd.z;
+            gcnt[lane] = 0u, gtrav[lane] = 0u, gT[lane] = 1.0f;
+        }
         seg_lo = near_plane, seg_hi = far_plane;
         for (seg = 0; seg < 3; seg++) {
             if (seg == 1) {
@@ -396,6 +416,154 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                     }
                 }
             }
+        } else if (group_walk) {
+            // ---- group walk: EIGHT LANES PER RAY. Lane m of a group tests child slot m of the ray's current node, so one
+            // 16-B load per lane fetches the whole 128-B node (one line per group and instruction instead of eight divergent
+            // loads per lane), the eight slab tests run in parallel, and a group works through its eight rays one after
+            // the other - its load is the SUM of eight rays (per-lane walks wait for the slowest of 64). Hit children are
+            // compacted with a ballot: inner nodes to the ray's LDS stack, leaves to the ray's queue (coalesced). Phase B
+            // evaluates a ray's queue eight entries at a time with the same groups. Rays stay in LDS (rayt).
+            const uint32_t g8 = (uint32_t)lane & ~7u, m = (uint32_t)lane & 7u, below = (1u << m) - 1u;
+            const size_t scratch0 = (size_t)blockIdx.x * EGR_WAVE;
+            uint32_t *__restrict__ gstk = v.stack_spill + (size_t)blockIdx.x * EGR_GSTK * EGR_WAVE;
+            bool g_over = false;
+            gsp[lane] = ((act_mask >> lane) & 1ull) ? 1u : 0u; // finite ray of an active lane: one pending entry, the root
+            lstk[0][lane] = 0u;
+            // Rounds of (walk, evaluate): a ray whose leaf queue fills up is suspended - its stack column stays where it is -
+            // and resumes after the evaluation phase has drained the queue (the reference's candidate pool is global, a
+            // single grazing ray may overlap thousands of gaussians).
+            for (;;) {
+            gq[lane] = 0u;
+            __syncthreads();
+            {   // ---------------- phase A
+                uint32_t r = 0xFFFFFFFFu, j = g8, sp = 0, nq = 0;
+                bool done = false;
+                f3 ginv = mk3(0, 0, 0), gnc = mk3(0, 0, 0);
+                uint32_t *__restrict__ queue_j = v.cand_queue;
+                for (;;) {
+                    if ((sp == 0u || nq + 2u * EGR_WIDTH > v.cand_cap) && !done) { // group-uniform: close (finished or queue full), open the next
+                        if (r != 0xFFFFFFFFu && m == 0u) gq[j] = nq, gsp[j] = sp;
+                        bool found = false;
+                        while (++r < 8u) {
+                            j = g8 + r;
+                            if (gsp[j] != 0u) { found = true; break; } // unfinished ray
+                        }
+                        if (!found) {
+                            done = true;
+                        } else {
+                            const f3 o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
+                            ginv = mk3(1.0f / (d.x * v.frame.sx), 1.0f / (d.y * v.frame.sy), 1.0f / (d.z * v.frame.sz));
+                            gnc = mk3(-((o.x - v.frame.ox) * v.frame.sx + 2.0f) * ginv.x, -((o.y - v.frame.oy) * v.frame.sy + 2.0f) * ginv.y,
+                                      -((o.z - v.frame.oz) * v.frame.sz + 2.0f) * ginv.z);
+                            queue_j = v.cand_queue + (scratch0 + j) * v.cand_cap;
+                            nq = 0u, sp = gsp[j];
+                        }
+                    }
+                    if (__ballot(!done) == 0ull) break;
+                    if (!done) {
+                        // pop up to two nodes: two independent line fetches in flight per group
+                        auto pop = [&]() {
+                            sp--;
+                            uint32_t w = lstk[min(sp, (uint32_t)EGR_LSTK - 1u)][j];
+                            if (sp >= EGR_LSTK) w = *reinterpret_cast<const volatile uint32_t *>(gstk + (size_t)(sp - EGR_LSTK) * EGR_WAVE + j);
+                            return w;
+                        };
+                        const uint32_t wa = pop();
+                        const bool two = sp > 0u;
+                        const uint32_t wb = two ? pop() : wa;
+                        const uint4 sa = wnodes[(size_t)wa * EGR_WIDTH + m];
+                        uint4 sb = make_uint4(0u, 0u, 0u, EGR_EMPTY_SLOT);
+                        if (two) sb = wnodes[(size_t)wb * EGR_WIDTH + m];
+#ifdef EGR_TRAVERSAL_STATS
+                        st_visits += (m == 0u) ? (two ? 2u : 1u) : 0u;
+                        if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
+#endif
+                        auto process = [&](const uint4 &sl) {
+                            const bool hit = sl.w != EGR_EMPTY_SLOT && qslab_hit(sl, ginv, gnc, seg_lo, seg_hi);
+                            const bool leaf = (sl.w & EGR_LEAF_FLAG) != 0u;
+                            const uint32_t gi = (uint32_t)(__ballot(hit && !leaf) >> g8) & 0xFFu, gl = (uint32_t)(__ballot(hit && leaf) >> g8) & 0xFFu;
+                            if (hit && !leaf) {
+                                const uint32_t at = sp + (uint32_t)__popc(gi & below);
+                                if (at < EGR_LSTK) lstk[at][j] = sl.w;
+                                else if (at < EGR_LSTK + EGR_GSTK) gstk[(size_t)(at - EGR_LSTK) * EGR_WAVE + j] = sl.w;
+                                else g_over = true;
+                            }
+                            sp = min(sp + (uint32_t)__popc(gi), (uint32_t)(EGR_LSTK + EGR_GSTK));
+                            if (hit && leaf) {
+                                const uint32_t at = nq + (uint32_t)__popc(gl & below);
+                                if (at < v.cand_cap) queue_j[at] = sl.w & ~EGR_LEAF_FLAG;
+                                else g_over = true;
+                            }
+                            nq = min(nq + (uint32_t)__popc(gl), v.cand_cap);
+                        };
+                        process(sa);
+                        process(sb);
+                    }
+                }
+            }
+            __syncthreads();
+            {   // ---------------- phase B
+                uint32_t r = 0xFFFFFFFFu, j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0;
+                bool done = false;
+                float Tpart = 1.0f;
+                f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+                const uint32_t *__restrict__ queue_j = v.cand_queue;
+                float *__restrict__ keys_j = v.cand_keys;
+                float2 *__restrict__ vals_j = v.cand_vals;
+                for (;;) {
+                    if (k0 >= nqj && !done) { // group-uniform: close the finished ray, open the next one with queued leaves
+                        if (r != 0xFFFFFFFFu) {
+                            float Tp = Tpart; // product of the eight lanes' partial products (deterministic order)
+                            Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 1)), Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 2)), Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 4));
+                            if (m == 0u) gcnt[j] = cntg, gtrav[j] += travg, gT[j] = (float)((double)gT[j] * (double)Tp);
+                        }
+                        bool found = false;
+                        while (++r < 8u) {
+                            j = g8 + r;
+                            if (gq[j] != 0u) { found = true; break; }
+                        }
+                        if (!found) {
+                            done = true;
+                        } else {
+                            o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
+                            queue_j = v.cand_queue + (scratch0 + j) * v.cand_cap;
+                            keys_j = v.cand_keys + (scratch0 + j) * v.cand_cap, vals_j = v.cand_vals + (scratch0 + j) * v.cand_cap;
+                            nqj = gq[j], k0 = 0u, cntg = gcnt[j], travg = 0u, Tpart = 1.0f;
+                        }
+                    }
+                    if (__ballot(!done) == 0ull) break;
+                    if (!done) {
+                        const uint32_t k = k0 + m;
+                        const bool have = k < nqj;
+                        int res = 0;
+                        float t = 0.0f, alpha = 0.0f;
+                        uint32_t pidx = 0u;
+                        if (have) {
+                            pidx = queue_j[k];
+                            const float4 w0 = v.inst_w[4 * pidx], w1 = v.inst_w[4 * pidx + 1], w2 = v.inst_w[4 * pidx + 2];
+                            res = test_candidate(o, d, pidx, w0, w1, w2, v.inst_w + 4 * (size_t)pidx + 3, t, alpha);
+                        }
+#ifdef EGR_TRAVERSAL_STATS
+                        st_leafhits += have ? 1u : 0u;
+                        st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
+#endif
+                        const uint32_t gc = (uint32_t)(__ballot(res >= 1) >> g8) & 0xFFu, ga = (uint32_t)(__ballot(res == 2) >> g8) & 0xFFu;
+                        if (res == 2) {
+                            const uint32_t at = cntg + (uint32_t)__popc(ga & below);
+                            if (at < v.cand_cap) keys_j[at] = t, vals_j[at] = make_float2(alpha, u2f(pidx));
+                            else g_over = true;
+                            Tpart = (float)((double)Tpart * (1.0 - (double)alpha)); // :70 (Q1: over ALL accepted candidates)
+                        }
+                        cntg = min(cntg + (uint32_t)__popc(ga), v.cand_cap);
+                        travg += (uint32_t)__popc(gc);
+                        k0 += 8u;
+                    }
+                }
+            }
+            __syncthreads();
+            if (__ballot(gsp[lane] != 0u) == 0ull) break;
+            }
+            if (__ballot(g_over) != 0ull) overflow = true;
         } else {
             // ---- per-lane walk: DFS with a per-lane stack (LDS [depth][lane], conflict-free; deeper entries spill to a
             // per-wave global column). Phase A queues the leaves whose box the lane's segment overlaps, phase B evaluates
@@ -476,6 +644,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         }
 
         }
+        if (group_walk) cnt = gcnt[lane], traversed = gtrav[lane], full_T = gT[lane];
 #ifdef EGR_TRAVERSAL_STATS
         const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
         {
@@ -1111,6 +1280,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
     v.group_lanes = c->group_lanes;
+    v.group_walk = c->group_walk;
     v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
     return v;
 }
