@@ -289,7 +289,7 @@ __device__ __forceinline__ uint4 pack_box(const uint32_t lo[3], const uint32_t h
 // One level of the wide tree: every child slot's box. Leaf slot: the gaussian's (padded) world box. Internal slot: the
 // union of the child node's 8 slot boxes - the child lives in a deeper level that an earlier launch already refitted.
 __global__ void __launch_bounds__(BS) k_refit_wide_level(uint32_t begin, uint32_t end, const float *__restrict__ aabb,
-                                                         const uint32_t *__restrict__ gid_of_pos, BvhFrame fr, uint4 *wnodes) {
+                                                         const uint32_t *__restrict__ gid_of_pos, BvhFrame fr, uint4 *wnodes, uint32_t *__restrict__ out_of_frame) {
     const uint32_t slot = blockIdx.x * BS + threadIdx.x; // one thread per child slot
     const uint32_t w = begin + slot / EGR_WIDTH, k = slot % EGR_WIDTH;
     if (w >= end) return;
@@ -303,6 +303,8 @@ __global__ void __launch_bounds__(BS) k_refit_wide_level(uint32_t begin, uint32_
             const float fo[3] = {fr.ox, fr.oy, fr.oz}, fs[3] = {fr.sx, fr.sy, fr.sz};
 #pragma unroll
             for (int a = 0; a < 3; a++) lo[a] = quant_lo(bx[a], fo[a], fs[a]), hi[a] = quant_hi(bx[3 + a], fo[a], fs[a]);
+            // a box that left the build frame carries the -inf / +inf sentinel cells: the traversal then takes its slower decode
+            if (lo[0] == 0u || lo[1] == 0u || lo[2] == 0u || hi[0] == 65535u || hi[1] == 65535u || hi[2] == 65535u) atomicOr(out_of_frame, 1u);
         }
     } else {
         const uint4 *ch = wnodes + (size_t)link * EGR_WIDTH;
@@ -331,7 +333,7 @@ template <class T> void dalloc(T *&p, size_t count) {
 void egr_bvh_free(egr_context *c) {
     dfree(c->wnodes), dfree(c->pos_of_gid), dfree(c->inst_w), dfree(c->inst_m), dfree(c->app), dfree(c->aabb), dfree(c->grad_rows);
     dfree(c->sort_tmp), dfree(c->keys_in), dfree(c->keys_out), dfree(c->vals_in), dfree(c->vals_out);
-    dfree(c->k_left), dfree(c->k_right), dfree(c->k_parent), dfree(c->k_first), dfree(c->k_last), dfree(c->wide_of), dfree(c->scratch_u32);
+    dfree(c->k_left), dfree(c->k_right), dfree(c->k_parent), dfree(c->k_first), dfree(c->k_last), dfree(c->wide_of), dfree(c->scratch_u32), dfree(c->out_of_frame);
     c->n_alloc = 0;
     c->n_built = 0;
     c->bvh_valid = false;
@@ -352,6 +354,10 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
     dalloc(c->k_left, cap), dalloc(c->k_right, cap), dalloc(c->k_parent, 2 * (size_t)cap);
     dalloc(c->k_first, cap), dalloc(c->k_last, cap), dalloc(c->wide_of, cap);
     if (!c->scratch_u32) dalloc(c->scratch_u32, 64);
+    if (!c->out_of_frame) {
+        dalloc(c->out_of_frame, 1);
+        EGR_HIP(hipMemset(c->out_of_frame, 0, sizeof(uint32_t)));
+    }
     size_t bytes = 0;
     EGR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)cap, 0, 63, 0));
     dfree(c->sort_tmp);
@@ -362,12 +368,13 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
 }
 
 static void refit_boxes(egr_context *c, hipStream_t s) {
+    EGR_HIP(hipMemsetAsync(c->out_of_frame, 0, sizeof(uint32_t), s));
     // level_start[L]..level_start[L+1] = wide nodes of level L (root = level 0). Deepest level first.
     for (int L = (int)c->level_start.size() - 2; L >= 0; L--) {
         const uint32_t b = c->level_start[L], e = c->level_start[L + 1];
         if (e > b)
             hipLaunchKernelGGL(k_refit_wide_level, dim3(nblk((uint64_t)(e - b) * EGR_WIDTH)), dim3(BS), 0, s, b, e, c->aabb, c->vals_out, c->frame,
-                               c->wnodes);
+                               c->wnodes, c->out_of_frame);
     }
 }
 

@@ -64,6 +64,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     const uint32_t *gid_of_pos; // [n] gaussian id stored at sorted position p
     const uint32_t *pos_of_gid; // [n] inverse
     BvhFrame frame;
+    const uint32_t *out_of_frame; // != 0: some box carries the -inf / +inf sentinel cells (see qslab_hit)
     const float4 *inst_w;
     const float4 *inst_m;       // [n][4] backward record: rows 0-2 = (M row, exp(scale_a)), row 3 = raw quaternion
     float *grad_rows;           // [n][32] gradient accumulation rows in record order (one 128-B line per gaussian)
@@ -138,6 +139,7 @@ struct egr_context {
     BvhFrame frame{0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
     float4 *inst_w = nullptr, *inst_m = nullptr, *app = nullptr;
     float *aabb = nullptr;             // [n][6] instance boxes (lo, hi)
+    uint32_t *out_of_frame = nullptr;  // device flag written by the refit
     float *grad_rows = nullptr;        // [n_alloc][32] zero between launches (k_grad_gather empties what it reads)
     uint32_t max_depth = 0;
     // build temporaries

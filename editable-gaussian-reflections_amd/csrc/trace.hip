@@ -146,6 +146,17 @@ EGR_DI bool qslab_hit(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return t0 <= t1;
 }
+// Same test when no box of the tree left the build frame (the common case; DeviceView::out_of_frame == 0): no sentinels.
+EGR_DI bool qslab_hit_inframe(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
+    const float flx = (float)(q.x & 0xFFFFu), fly = (float)(q.x >> 16), flz = (float)(q.y & 0xFFFFu);
+    const float fhx = (float)(q.y >> 16), fhy = (float)(q.z & 0xFFFFu), fhz = (float)(q.z >> 16);
+    const float ax = fmaf(flx, invq.x, ncq.x), bx = fmaf(fhx, invq.x, ncq.x);
+    const float ay = fmaf(fly, invq.y, ncq.y), by = fmaf(fhy, invq.y, ncq.y);
+    const float az = fmaf(flz, invq.z, ncq.z), bz = fmaf(fhz, invq.z, ncq.z);
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return t0 <= t1;
+}
 EGR_DI float4 fetch_a2(const float4 *p) { return *p; }
 EGR_DI float4 fetch_a2(float4 v) { return v; }
 // OptiX's instance test restated: segment [tmin,tmax] of the object-space ray vs the unit cube.
@@ -226,6 +237,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     const float4 *__restrict__ app = v.app;
     const uint32_t END = v.num_nodes;
 
+    const bool sentinels = __builtin_amdgcn_readfirstlane((int)*v.out_of_frame) != 0;
     const float exp_power = *v.cfg.exp_power;
     const float transmittance_threshold = *v.cfg.transmittance_threshold;
     const float backfacing_max_dist = *v.cfg.backfacing_max_dist;
@@ -291,6 +303,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #endif
         int seg = 0;                 // which of the three walked segments is active (see the walk below)
         float seg_lo, seg_hi;
+        auto slab = [&](const uint4 &q, const f3 &iq, const f3 &nq_) { // wave-uniform choice of the decode
+            return sentinels ? qslab_hit(q, iq, nq_, seg_lo, seg_hi) : qslab_hit_inframe(q, iq, nq_, seg_lo, seg_hi);
+        };
         // R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record.
         // `prim` is the gaussian's SORTED POSITION (record index), not its id.
         // returns 0: not counted, 1: counted (reached the reference's intersection program), 2: accepted (t, alpha valid)
@@ -396,7 +411,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 for (int k = 0; k < EGR_WIDTH; k++) {
                     const uint4 sl = load_u4_uniform(wnodes, w * EGR_WIDTH + (uint32_t)k);
                     if (sl.w == EGR_EMPTY_SLOT) break; // uniform: slots are packed from 0
-                    const bool hit = ray_ok && qslab_hit(sl, invq, ncq, seg_lo, seg_hi);
+                    const bool hit = ray_ok && slab(sl, invq, ncq);
                     if (__ballot(hit) == 0ull) continue;
 #ifdef EGR_TRAVERSAL_STATS
                     st_visits += hit ? 1u : 0u;
@@ -479,7 +494,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
 #endif
                         auto process = [&](const uint4 &sl) {
-                            const bool hit = sl.w != EGR_EMPTY_SLOT && qslab_hit(sl, ginv, gnc, seg_lo, seg_hi);
+                            const bool hit = sl.w != EGR_EMPTY_SLOT && slab(sl, ginv, gnc);
                             const bool leaf = (sl.w & EGR_LEAF_FLAG) != 0u;
                             const uint32_t gi = (uint32_t)(__ballot(hit && !leaf) >> g8) & 0xFFu, gl = (uint32_t)(__ballot(hit && leaf) >> g8) & 0xFFu;
                             if (hit && !leaf) {
@@ -603,7 +618,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #pragma unroll
                     for (int k = EGR_WIDTH - 1; k >= 0; k--) { // reverse: slot 0 is popped first
                         if (sl[k].w == EGR_EMPTY_SLOT) continue;
-                        if (!qslab_hit(sl[k], invq, ncq, seg_lo, seg_hi)) continue;
+                        if (!slab(sl[k], invq, ncq)) continue;
                         if (sl[k].w & EGR_LEAF_FLAG) {
                             const uint32_t id = sl[k].w & ~EGR_LEAF_FLAG;
                             pend.x = np == 0u ? id : pend.x, pend.y = np == 1u ? id : pend.y, pend.z = np == 2u ? id : pend.z, pend.w = np == 3u ? id : pend.w;
@@ -1274,7 +1289,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.task_begin = 0, v.task_count = v.num_tasks, v.queues = c->queues, v.num_strands = (uint32_t)c->strands;
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
-    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
+    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
