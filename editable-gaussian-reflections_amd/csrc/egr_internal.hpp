@@ -98,6 +98,7 @@ enum ControlWord : int {
     CW_QUEUE0 = 0,      // task queue heads, one per step kernel (forward 0..2, backward 3..5)
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
+    CW_BUCKET_RECORDS = 7, // records summed by k_bucket_reduce in this launch
     CW_RAYS = 10,       // per-step 64-bit counters (two words each): rays[3], candidates[3], composited[3]
     CW_CAND = 16,
     CW_COMP = 22,

@@ -378,10 +378,10 @@ struct Raytracer : torch::CustomClassHolder {
     std::vector<int64_t> get_counters() { // synchronises
         egr_counters c{};
         check(egr_get_counters(ctx, &c, current_stream()), "get_counters");
-        // [rays0..2, candidates0..2, composited0..2, lifetime_rays, lifetime_launches, status, bvh_depth]
+        // [rays0..2, candidates0..2, composited0..2, lifetime_rays, lifetime_launches, status, bvh_depth, bucket_records]
         return {(int64_t)c.rays[0], (int64_t)c.rays[1], (int64_t)c.rays[2], (int64_t)c.candidates[0], (int64_t)c.candidates[1],
                 (int64_t)c.candidates[2], (int64_t)c.composited[0], (int64_t)c.composited[1], (int64_t)c.composited[2],
-                (int64_t)c.lifetime_rays, (int64_t)c.lifetime_launches, (int64_t)c.status, (int64_t)c.bvh_depth};
+                (int64_t)c.lifetime_rays, (int64_t)c.lifetime_launches, (int64_t)c.status, (int64_t)c.bvh_depth, (int64_t)c.bucket_records};
     }
     void reset_lifetime_counters() { check(egr_reset_lifetime_counters(ctx, current_stream()), "reset_lifetime_counters"); }
     void enable_timing(bool on) { egr_enable_timing(ctx, on ? 1 : 0); }
@@ -468,6 +468,19 @@ struct Raytracer : torch::CustomClassHolder {
             .def("debug_instances", &Raytracer::debug_instances);
     }
 };
+
+// simple_knn._C.distCUDA2 (gaussian_model.py:17): float CUDA(HIP) tensor [N,3] -> [N] mean squared distance to the 3 nearest
+// neighbours. Registered as torch.ops.simple_knn.distCUDA2; the package's simple_knn.py re-exports it under the reference's name.
+static torch::Tensor dist_hip2(const torch::Tensor &points) {
+    TORCH_CHECK(points.is_cuda(), "distCUDA2: points must live on the GPU (there is no CPU path)");
+    TORCH_CHECK(points.dim() == 2 && points.size(1) == 3, "distCUDA2: expected an [N,3] tensor");
+    auto p = points.to(torch::kFloat32).contiguous();
+    auto out = torch::zeros({p.size(0)}, p.options());
+    const int rc = egr_knn_mean_dist2(p.get_device(), p.data_ptr<float>(), (uint32_t)p.size(0), out.data_ptr<float>(), current_stream());
+    TORCH_CHECK(rc == 0, egr_knn_last_error());
+    return out;
+}
+TORCH_LIBRARY(simple_knn, m) { m.def("distCUDA2(Tensor points) -> Tensor", &dist_hip2); }
 
 TORCH_LIBRARY(raytracer, m) {
     CameraDataHolder::bind(m);

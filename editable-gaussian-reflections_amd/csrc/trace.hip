@@ -1060,6 +1060,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
     if (begin >= count) return;
     const uint32_t end = min(count, begin + EGR_BUCKET_SLICE);
     const bool shared_bucket = count > EGR_BUCKET_SLICE; // several workgroups add into the same rows
+    if (threadIdx.x == 0) atomicAdd(v.control + CW_BUCKET_RECORDS, end - begin);
     for (int i = threadIdx.x; i < BG * 17; i += 256) acc[i] = 0.0f;
     __syncthreads();
     const float4 *src = v.gb_data + (size_t)bucket * v.gb_cap * 4;

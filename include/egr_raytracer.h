@@ -103,7 +103,7 @@ typedef struct egr_counters {
     uint32_t lifetime_launches;
     uint32_t status;                     /* EGR_STATUS_* bit mask of the last launch                          */
     uint32_t bvh_depth;
-    uint32_t reserved;
+    uint32_t bucket_records;             /* gradient records the bounce-step backward appended (grad launches) */
 } egr_counters;
 
 #define EGR_STATUS_OK 0u
@@ -174,6 +174,13 @@ int egr_debug_check_bvh(egr_context *ctx, void *hip_stream);
 
 const char *egr_last_error(egr_context *ctx);
 const char *egr_version(void);
+
+/* ---- `simple_knn._C.distCUDA2` (editable_gauss_refl/scene/gaussian_model.py:17, called at :197-201 and
+ * :246-250 to initialise the scales). out[i] = mean of the squared distances from point i to its 3 nearest OTHER points
+ * (exact; duplicates count with distance 0). points_xyz = [n][3] fp32, out = [n] fp32, both device pointers. Synchronises the
+ * stream before returning (it frees its temporaries). Returns 0 on success; egr_knn_last_error() describes a failure. */
+int egr_knn_mean_dist2(int device, const float *points_xyz, uint32_t n, float *out_mean_dist2, void *hip_stream);
+const char *egr_knn_last_error(void);
 
 #ifdef __cplusplus
 }
