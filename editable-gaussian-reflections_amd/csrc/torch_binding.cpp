@@ -480,7 +480,45 @@ static torch::Tensor dist_hip2(const torch::Tensor &points) {
     TORCH_CHECK(rc == 0, egr_knn_last_error());
     return out;
 }
+// One launch for import + scale decay + Adam + clamps + zero_grad + export (csrc/step.hip). Tensor lists are parallel, one
+// entry per parameter group; an undefined / empty tensor means "absent" for grads, rt_params, rt_grads and the Adam moments.
+static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch::Tensor> grads, std::vector<torch::Tensor> rt_params,
+                            std::vector<torch::Tensor> rt_grads, std::vector<torch::Tensor> exp_avg, std::vector<torch::Tensor> exp_avg_sq,
+                            std::vector<double> lrs, std::vector<double> clamp_min, std::vector<double> clamp_max, std::vector<double> log_decay,
+                            int64_t step, double beta1, double beta2, double eps) {
+    const size_t G = params.size();
+    TORCH_CHECK(G >= 1 && G <= EGR_MAX_PARAM_GROUPS, "fused_adam_step: 1..8 parameter groups");
+    TORCH_CHECK(grads.size() == G && rt_params.size() == G && rt_grads.size() == G && exp_avg.size() == G && exp_avg_sq.size() == G && lrs.size() == G &&
+                    clamp_min.size() == G && clamp_max.size() == G && log_decay.size() == G,
+                "fused_adam_step: all lists need one entry per group");
+    egr_param_group g[EGR_MAX_PARAM_GROUPS];
+    const int64_t n = params[0].size(0);
+    auto ptr = [&](const torch::Tensor &t, const torch::Tensor &like, const char *what) -> float * {
+        if (!t.defined() || t.numel() == 0) return nullptr;
+        TORCH_CHECK(t.is_cuda() && t.scalar_type() == torch::kFloat32 && t.is_contiguous() && t.numel() == like.numel(), "fused_adam_step: ", what,
+                    " must be a contiguous float GPU tensor of the parameter's size");
+        return t.data_ptr<float>();
+    };
+    for (size_t k = 0; k < G; k++) {
+        TORCH_CHECK(params[k].is_cuda() && params[k].scalar_type() == torch::kFloat32 && params[k].is_contiguous() && params[k].size(0) == n,
+                    "fused_adam_step: parameters must be contiguous float GPU tensors with the same leading size");
+        g[k].param = params[k].data_ptr<float>();
+        g[k].grad = ptr(grads[k], params[k], "grad"), g[k].rt_param = ptr(rt_params[k], params[k], "rt_param");
+        g[k].rt_grad = ptr(rt_grads[k], params[k], "rt_grad");
+        g[k].exp_avg = ptr(exp_avg[k], params[k], "exp_avg"), g[k].exp_avg_sq = ptr(exp_avg_sq[k], params[k], "exp_avg_sq");
+        g[k].width = n ? (uint32_t)(params[k].numel() / n) : 1u;
+        g[k].lr = (float)lrs[k], g[k].clamp_min = (float)clamp_min[k], g[k].clamp_max = (float)clamp_max[k], g[k].log_decay = (float)log_decay[k];
+    }
+    const int rc = egr_fused_adam_step(params[0].get_device(), g, (int)G, (uint32_t)n, (uint32_t)step, beta1, beta2, eps, current_stream());
+    TORCH_CHECK(rc == 0, egr_fused_step_last_error());
+}
+
 TORCH_LIBRARY(simple_knn, m) { m.def("distCUDA2(Tensor points) -> Tensor", &dist_hip2); }
+TORCH_LIBRARY(egr, m) {
+    m.def("fused_adam_step(Tensor[] params, Tensor[] grads, Tensor[] rt_params, Tensor[] rt_grads, Tensor[] exp_avg, Tensor[] exp_avg_sq, float[] lrs, "
+          "float[] clamp_min, float[] clamp_max, float[] log_decay, int step, float beta1, float beta2, float eps) -> ()",
+          &fused_adam_step);
+}
 
 TORCH_LIBRARY(raytracer, m) {
     CameraDataHolder::bind(m);

@@ -1,0 +1,69 @@
+"""Host step of one training iteration as ONE HIP launch.
+
+Mirrors what the reference does around `render()` in train.py:217-254 with ~60 small torch kernels:
+gradient import (renderer/gaussian_raytracer.py:53-62), scale decay (train.py:224-226), `gaussians.optimizer.step()` =
+torch.optim.Adam(eps=1e-15, betas=(beta_1, beta_2)) over the eight parameter groups of scene/gaussian_model.py:296-338,
+`zero_grad` of the model and of the raytracer (train.py:248-249), the three clamps (train.py:251-254) and the parameter
+export the next `GaussianRaytracer.__call__` would do (gaussian_raytracer.py:41-50). `expon_lr` restates
+utils/general_utils.py:31-60 (pinned by tests/golden/expon_lr.npz, generated from the reference's own function).
+"""
+import importlib
+import math
+
+import numpy as np
+import torch
+
+importlib.import_module(__package__).load_library()
+
+# (optimizer group name, model attribute, raytracer tensor) in the order of gaussian_model.py:296-326
+GROUPS = (("xyz", "_xyz", "mean"), ("normal", "_normal", "normal"), ("roughness", "_roughness", "roughness"), ("f0", "_f0", "f0"),
+          ("f_dc", "_diffuse", "rgb"), ("opacity", "_opacity", "opacity"), ("scaling", "_scaling", "scale"), ("rotation", "_rotation", "rotation"))
+CLAMPS = {"f_dc": (0.0, math.inf), "roughness": (0.0, 1.0), "f0": (0.0, 1.0)}  # train.py:251-254
+
+
+def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils/general_utils.py:31-60 (get_expon_lr_func's helper): log-linear interpolation with an optional delayed start."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+    else:
+        delay_rate = 1.0
+    t = np.clip(step / max_steps, 0, 1)
+    return float(delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+
+class FusedTrainStep:
+    """`step()` = import + scale decay + Adam + clamps + both zero_grads + export, one kernel over all eight groups.
+
+    pc: model with the reference's raw parameter attributes (each with a `.grad`); raytracer: renderer.GaussianRaytracer;
+    lrs: {group name: learning rate}; xyz_schedule: kwargs of `expon_lr` (the reference only schedules xyz,
+    gaussian_model.py:349-355)."""
+
+    def __init__(self, pc, raytracer, lrs, beta1=0.9, beta2=0.999, eps=1e-15, scale_decay=1.0, xyz_schedule=None):
+        self.pc, self.rt = pc, raytracer
+        self.lrs = {name: float(lrs.get(name, 0.0)) for name, _, _ in GROUPS}
+        self.beta1, self.beta2, self.eps, self.scale_decay = beta1, beta2, eps, scale_decay
+        self.xyz_schedule = xyz_schedule
+        self.steps = 0
+        self.exp_avg = {name: torch.zeros_like(getattr(pc, attr)) for name, attr, _ in GROUPS}
+        self.exp_avg_sq = {name: torch.zeros_like(getattr(pc, attr)) for name, attr, _ in GROUPS}
+
+    def update_learning_rate(self, iteration):  # gaussian_model.py:349-355
+        if self.xyz_schedule is not None:
+            self.lrs["xyz"] = expon_lr(iteration, **self.xyz_schedule)
+        return self.lrs["xyz"]
+
+    @torch.no_grad()
+    def step(self):
+        g = self.rt.cuda_module.get_gaussians()
+        self.steps += 1
+        params = [getattr(self.pc, attr) for _, attr, _ in GROUPS]
+        grads = [getattr(self.pc, attr).grad for _, attr, _ in GROUPS]
+        rt_params = [getattr(g, rt) for _, _, rt in GROUPS]
+        rt_grads = [getattr(g, rt).grad for _, _, rt in GROUPS]
+        torch.ops.egr.fused_adam_step(
+            params, grads, rt_params, rt_grads, [self.exp_avg[n] for n, _, _ in GROUPS], [self.exp_avg_sq[n] for n, _, _ in GROUPS],
+            [self.lrs[n] for n, _, _ in GROUPS], [CLAMPS.get(n, (-math.inf, math.inf))[0] for n, _, _ in GROUPS],
+            [CLAMPS.get(n, (-math.inf, math.inf))[1] for n, _, _ in GROUPS], [self.scale_decay if n == "scaling" else 1.0 for n, _, _ in GROUPS],
+            self.steps, self.beta1, self.beta2, self.eps)

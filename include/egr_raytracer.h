@@ -182,6 +182,28 @@ const char *egr_version(void);
 int egr_knn_mean_dist2(int device, const float *points_xyz, uint32_t n, float *out_mean_dist2, void *hip_stream);
 const char *egr_knn_last_error(void);
 
+/* ---- the host step around every raytrace as ONE launch - gradient import
+ * (renderer/gaussian_raytracer.py:50-58), scale decay (train.py:224-226), torch.optim.Adam(eps=1e-15) over the 8 parameter
+ * groups (scene/gaussian_model.py:296-338), clamps (train.py:251-254), both zero_grads (train.py:248-249) and the parameter
+ * export of the next iteration (gaussian_raytracer.py:36-48). All pointers are device pointers to [n][width] fp32 arrays. */
+#define EGR_MAX_PARAM_GROUPS 8
+typedef struct egr_param_group {
+    float *param;       /* model parameter, updated in place                                              */
+    float *grad;        /* model gradient: read, then zeroed (NULL: none)                                   */
+    float *rt_param;    /* raytracer-side tensor refreshed with the new value (export; NULL: skip)          */
+    float *rt_grad;     /* raytracer-side gradient dL_d*: added to the gradient, then zeroed (NULL: skip)   */
+    float *exp_avg;     /* Adam first moment  (NULL together with exp_avg_sq: no optimizer update)          */
+    float *exp_avg_sq;  /* Adam second moment                                                               */
+    uint32_t width;     /* floats per gaussian                                                               */
+    float lr;           /* this iteration's learning rate of the group                                      */
+    float clamp_min, clamp_max; /* applied after the update (-INFINITY / +INFINITY: none)                    */
+    float log_decay;    /* != 1: param = log(exp(param) * log_decay) before the update (scale decay)        */
+} egr_param_group;
+/* `step` is Adam's 1-based step count of THIS update. Asynchronous on the stream. Returns 0 on success. */
+int egr_fused_adam_step(int device, const egr_param_group *groups, int num_groups, uint32_t n, uint32_t step, double beta1, double beta2,
+                        double eps, void *hip_stream);
+const char *egr_fused_step_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
