@@ -812,11 +812,32 @@ enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_
 // (~26 G/s measured) if every contribution is a global atomic. Instead ONE 64-B record per (tile, gaussian) - or per hit
 // when the LDS table is full - is appended to the bucket of its gaussian (256 Morton-consecutive gaussians, one returning
 // counter atomic); k_bucket_reduce then sums each bucket in LDS and writes the gradients without global atomics.
-EGR_DI bool bucket_append(const DeviceView &v, uint32_t pos, float d_opacity, f3 d_scale, f3 d_mean, float r0, float r1, float r2, float r3,
-                          f3 d_rgb, float weight) {
-    const uint32_t bucket = pos >> EGR_BUCKET_SHIFT;
-    const uint32_t at = atomicAdd(v.gb_count + bucket, 1u);
+// Slot allocation is WAVE-AGGREGATED: the tiles of a bounce step hit neighbouring gaussians, so most lanes of one append want
+// the same bucket, and 64 returning atomics on one counter serialise in the L2 (measured: skipping the LDS table, i.e. 33 %
+// more appends, doubled the kernel time). One lane per distinct bucket adds the group's size; every lane gets base + rank.
+// All distinct buckets' atomics are in flight together (their results are only consumed after the loop).
+// Must be called by all lanes of the wave (wave-uniform control flow). Returns the record index, 0xFFFFFFFF for !need.
+EGR_DI uint32_t bucket_alloc_wave(const DeviceView &v, bool need, uint32_t bucket) {
+    const int lane = threadIdx.x;
+    unsigned long long M = __ballot(need);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t my_leader = 0, my_rank = 0, base_mine = 0;
+    while (M) {
+        const int L = __ffsll((long long)M) - 1;
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bucket, L);
+        const bool mine = need && bucket == b;
+        const unsigned long long S = __ballot(mine);
+        if (mine) my_leader = (uint32_t)L, my_rank = (uint32_t)__popcll(S & below);
+        if (lane == L) base_mine = atomicAdd(v.gb_count + b, (uint32_t)__popcll(S));
+        M &= ~S;
+    }
+    const uint32_t base = (uint32_t)__shfl((int)base_mine, (int)my_leader);
+    return need ? base + my_rank : 0xFFFFFFFFu;
+}
+EGR_DI bool bucket_store(const DeviceView &v, uint32_t pos, uint32_t at, float d_opacity, f3 d_scale, f3 d_mean, float r0, float r1, float r2, float r3,
+                         f3 d_rgb, float weight) {
     if (at >= v.gb_cap) return false; // bucket full: the caller falls back to atomics (correct, slower)
+    const uint32_t bucket = pos >> EGR_BUCKET_SHIFT;
     float4 *dst = v.gb_data + ((size_t)bucket * v.gb_cap + at) * 4;
     dst[0] = make_float4(u2f(pos & ((1u << EGR_BUCKET_SHIFT) - 1u)), d_opacity, d_scale.x, d_scale.y);
     dst[1] = make_float4(d_scale.z, d_mean.x, d_mean.y, d_mean.z);
@@ -827,20 +848,27 @@ EGR_DI bool bucket_append(const DeviceView &v, uint32_t pos, float d_opacity, f3
 
 EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_keys, float *gt_vals, int lane) {
     __syncthreads();
-    for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) {
+    for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: the bucket allocation below is a wave-level operation
+        const int s = s0 + lane;
         const uint32_t pos = gt_keys[s];
-        if (pos == EGR_GT_EMPTY) continue;
+        const bool valid = pos != EGR_GT_EMPTY;
         gt_keys[s] = EGR_GT_EMPTY;
         float x[EGR_GT_COMPS];
 #pragma unroll
-        for (int c = 0; c < EGR_GT_COMPS; c++) x[c] = gt_vals[c * EGR_GT_SLOTS + s], gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
-        if (bucketed && bucket_append(v, pos, x[GC_OPA], mk3(x[GC_SCALE], x[GC_SCALE + 1], x[GC_SCALE + 2]), mk3(x[GC_MEAN], x[GC_MEAN + 1], x[GC_MEAN + 2]),
-                                      x[GC_ROT], x[GC_ROT + 1], x[GC_ROT + 2], x[GC_ROT + 3], mk3(x[GC_RGB], x[GC_RGB + 1], x[GC_RGB + 2]), x[GC_WEIGHT]))
-            continue; // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
-        float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all 22 components of a gaussian share one line
+        for (int c = 0; c < EGR_GT_COMPS; c++) x[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f, gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
+        bool stored = false;
+        if (bucketed && __ballot(valid) != 0ull) { // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
+            const uint32_t at = bucket_alloc_wave(v, valid, pos >> EGR_BUCKET_SHIFT);
+            if (valid)
+                stored = bucket_store(v, pos, at, x[GC_OPA], mk3(x[GC_SCALE], x[GC_SCALE + 1], x[GC_SCALE + 2]), mk3(x[GC_MEAN], x[GC_MEAN + 1], x[GC_MEAN + 2]),
+                                      x[GC_ROT], x[GC_ROT + 1], x[GC_ROT + 2], x[GC_ROT + 3], mk3(x[GC_RGB], x[GC_RGB + 1], x[GC_RGB + 2]), x[GC_WEIGHT]);
+        }
+        if (valid && !stored) {
+            float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all 22 components of a gaussian share one line
 #pragma unroll
-        for (int c = 0; c < EGR_GT_COMPS; c++)
-            if (x[c] != 0.0f) atomicAdd(row + c, x[c]);
+            for (int c = 0; c < EGR_GT_COMPS; c++)
+                if (x[c] != 0.0f) atomicAdd(row + c, x[c]);
+        }
     }
     __syncthreads();
 }
@@ -923,6 +951,11 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
             for (int row = EGR_HIT_BLOCK_ROWS - 1; row >= 0; row--) {
                 const uint32_t it = b * EGR_HIT_BLOCK_ROWS + (uint32_t)row;
                 if (it >= max_hits) continue;
+                // a hit that finds no table slot leaves the divergent block with its gradients in `dg`: the bucket append that
+                // follows is a wave-level operation
+                bool direct = false;
+                uint32_t dpos = 0;
+                float dg[GC_NORMAL]; // the 15 components a bounce step produces
                 if (it < nhits) {
                     const float4 rec = rows[(size_t)(1 + row) * EGR_WAVE + lane];
                     const uint32_t pos = f2u(rec.x);          // record index (sorted position)
@@ -1022,9 +1055,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                         }
                         EGR_TA(GC_WEIGHT, weight)
 #undef EGR_TA
-                    } else if (bucketed && bucket_append(v, pos, d_opacity, d_scale, d_mean, d_rot0, d_rot1, d_rot2, d_rot3, d_rgb, weight)) {
-                        // table full for this gaussian: straight to its bucket
-                    } else {
+                    } else if (!bucketed) { // no buckets (primary step, or disabled): atomics on the gaussian's gradient row
                         float *grow = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE;
                         atomicAdd(grow + GC_OPA, d_opacity);
                         atomicAdd(grow + GC_SCALE, d_scale.x), atomicAdd(grow + GC_SCALE + 1, d_scale.y), atomicAdd(grow + GC_SCALE + 2, d_scale.z);
@@ -1037,6 +1068,27 @@ __global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
                             atomicAdd(grow + GC_ROUGH, d_rough);
                         }
                         atomicAdd(grow + GC_WEIGHT, weight);
+                    } else {
+                        direct = true, dpos = pos;
+                        dg[GC_OPA] = d_opacity, dg[GC_SCALE] = d_scale.x, dg[GC_SCALE + 1] = d_scale.y, dg[GC_SCALE + 2] = d_scale.z;
+                        dg[GC_MEAN] = d_mean.x, dg[GC_MEAN + 1] = d_mean.y, dg[GC_MEAN + 2] = d_mean.z;
+                        dg[GC_ROT] = d_rot0, dg[GC_ROT + 1] = d_rot1, dg[GC_ROT + 2] = d_rot2, dg[GC_ROT + 3] = d_rot3;
+                        dg[GC_RGB] = d_rgb.x, dg[GC_RGB + 1] = d_rgb.y, dg[GC_RGB + 2] = d_rgb.z, dg[GC_WEIGHT] = weight;
+                    }
+                }
+                if (__ballot(direct) != 0ull) { // table full for these gaussians (bucketed steps only)
+                    bool stored = false;
+                    { // straight to the bucket (one counter atomic per distinct bucket of the wave)
+                        const uint32_t at = bucket_alloc_wave(v, direct, dpos >> EGR_BUCKET_SHIFT);
+                        if (direct)
+                            stored = bucket_store(v, dpos, at, dg[GC_OPA], mk3(dg[GC_SCALE], dg[GC_SCALE + 1], dg[GC_SCALE + 2]),
+                                                  mk3(dg[GC_MEAN], dg[GC_MEAN + 1], dg[GC_MEAN + 2]), dg[GC_ROT], dg[GC_ROT + 1], dg[GC_ROT + 2], dg[GC_ROT + 3],
+                                                  mk3(dg[GC_RGB], dg[GC_RGB + 1], dg[GC_RGB + 2]), dg[GC_WEIGHT]);
+                    }
+                    if (direct && !stored) {
+                        float *grow = v.grad_rows + (size_t)dpos * EGR_ROW_STRIDE;
+#pragma unroll
+                        for (int c = 0; c < GC_NORMAL; c++) atomicAdd(grow + c, dg[c]);
                     }
                 }
             }
