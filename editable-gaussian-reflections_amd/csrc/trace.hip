@@ -873,7 +873,7 @@ EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_ke
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(EGR_WAVE) k_backward(DeviceView v, int step) {
+__global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward(DeviceView v, int step) {
     const int lane = threadIdx.x;
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
     __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
