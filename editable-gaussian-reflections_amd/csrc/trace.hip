@@ -439,6 +439,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             // compacted with a ballot: inner nodes to the ray's LDS stack, leaves to the ray's queue (coalesced). Phase B
             // evaluates a ray's queue eight entries at a time with the same groups. Rays stay in LDS (rayt).
             const uint32_t g8 = (uint32_t)lane & ~7u, m = (uint32_t)lane & 7u, below = (1u << m) - 1u;
+            const bool hi_half = lane >= 32;
+            const uint32_t gshift = g8 & 31u;
             const size_t scratch0 = (size_t)blockIdx.x * EGR_WAVE;
             uint32_t *__restrict__ gstk = v.stack_spill + (size_t)blockIdx.x * EGR_GSTK * EGR_WAVE;
             bool g_over = false;
@@ -450,6 +452,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             for (;;) {
             gq[lane] = 0u;
             __syncthreads();
+#ifdef EGR_TRAVERSAL_STATS
+            const unsigned long long tga0 = __builtin_amdgcn_s_memtime();
+#endif
             {   // ---------------- phase A
                 uint32_t r = 0xFFFFFFFFu, j = g8, sp = 0, nq = 0;
                 bool done = false;
@@ -487,16 +492,20 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         const bool two = sp > 0u;
                         const uint32_t wb = two ? pop() : wa;
                         const uint4 sa = wnodes[(size_t)wa * EGR_WIDTH + m];
-                        uint4 sb = make_uint4(0u, 0u, 0u, EGR_EMPTY_SLOT);
+                        uint4 sb = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, EGR_EMPTY_SLOT); // inverted box: never hit
                         if (two) sb = wnodes[(size_t)wb * EGR_WIDTH + m];
 #ifdef EGR_TRAVERSAL_STATS
                         st_visits += (m == 0u) ? (two ? 2u : 1u) : 0u;
                         if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
 #endif
                         auto process = [&](const uint4 &sl) {
-                            const bool hit = sl.w != EGR_EMPTY_SLOT && slab(sl, ginv, gnc);
-                            const bool leaf = (sl.w & EGR_LEAF_FLAG) != 0u;
-                            const uint32_t gi = (uint32_t)(__ballot(hit && !leaf) >> g8) & 0xFFu, gl = (uint32_t)(__ballot(hit && leaf) >> g8) & 0xFFu;
+                            const bool hit = sl.w != EGR_EMPTY_SLOT && slab(sl, ginv, gnc); // (the slab test orders the planes per axis: an inverted box is not empty)
+                            const bool leaf = (int)sl.w < 0;
+                            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit), lm = __builtin_amdgcn_ballot_w64(leaf);
+                            const unsigned long long im = hm & ~lm, fm = hm & lm; // scalar: inner / leaf children hit, whole wave
+                            // this lane's group: 8 bits of its 32-bit half
+                            const uint32_t gi = __builtin_amdgcn_ubfe(hi_half ? (uint32_t)(im >> 32) : (uint32_t)im, gshift, 8u);
+                            const uint32_t gl = __builtin_amdgcn_ubfe(hi_half ? (uint32_t)(fm >> 32) : (uint32_t)fm, gshift, 8u);
                             if (hit && !leaf) {
                                 const uint32_t at = sp + (uint32_t)__popc(gi & below);
                                 if (at < EGR_LSTK) lstk[at][j] = sl.w;
@@ -517,6 +526,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 }
             }
             __syncthreads();
+#ifdef EGR_TRAVERSAL_STATS
+            const unsigned long long tga1 = __builtin_amdgcn_s_memtime();
+#endif
             {   // ---------------- phase B
                 uint32_t r = 0xFFFFFFFFu, j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0;
                 bool done = false;
@@ -576,6 +588,12 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 }
             }
             __syncthreads();
+#ifdef EGR_TRAVERSAL_STATS
+            if (lane == 0) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0)), tga1 - tga0);
+                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0) + 2), __builtin_amdgcn_s_memtime() - tga1);
+            }
+#endif
             if (__ballot(gsp[lane] != 0u) == 0ull) break;
             }
             if (__ballot(g_over) != 0ull) overflow = true;
