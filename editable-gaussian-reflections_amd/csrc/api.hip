@@ -7,6 +7,7 @@
 #include "egr_internal.hpp"
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s);
+void egr_denoise_atrous(egr_context *c, hipStream_t s); // denoise.hip
 
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s) {
     if (!c->timing) return;
@@ -66,6 +67,7 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     if (const char *e = getenv("EGR_BUCKETED_BACKWARD")) c->bucketed_backward = atoi(e);
     if (const char *e = getenv("EGR_MORTON_SIZE")) c->morton_size_period = atoi(e);
     if (const char *e = getenv("EGR_GROUP_WALK")) c->group_walk = atoi(e);
+    if (const char *e = getenv("EGR_DENOISE")) c->denoise_mode = atoi(e);
     if (const char *e = getenv("EGR_STRANDS")) c->strands = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("EGR_GROUP_LANES")) {
         int g = atoi(e);
@@ -171,7 +173,10 @@ int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
 
 int egr_denoise(egr_context *c, void *stream) {
     if (!c || require_ready(c, false)) return 1;
-    return guarded(c, [&] { egr_copy_final_to_denoised(c, (hipStream_t)stream); });
+    return guarded(c, [&] {
+        if (c->denoise_mode == 0) egr_copy_final_to_denoised(c, (hipStream_t)stream); // EGR_DENOISE=0: plain copy
+        else egr_denoise_atrous(c, (hipStream_t)stream);
+    });
 }
 
 int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {

@@ -1315,7 +1315,7 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues);
+    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp);
     for (int i = 0; i < 4; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);

@@ -139,8 +139,9 @@ int egr_update_bvh(egr_context *ctx, void *hip_stream);
  * torch::autograd::GradMode::is_enabled() returned in the caller (metadata.h:29). Asynchronous. */
 int egr_raytrace(egr_context *ctx, int grads_enabled, void *hip_stream);
 
-/* Raytracer::denoise (raytracer.cpp:96; optix/denoiser_wrapper.h). The OptiX AI denoiser is a closed network and
- * is out of scope; this stand-in copies output_final into output_denoised so callers keep working. */
+/* Raytracer::denoise (raytracer.cpp:96; optix/denoiser_wrapper.h:42-105: HDR image output_final + normal guide output_normal
+ * -> output_denoised). The OptiX AI denoiser is a closed network; the stand-in is an edge-avoiding a-trous wavelet filter with
+ * the same inputs and output (csrc/denoise.hip; parity with OptiX is unpinned). Env EGR_DENOISE=0 at creation: plain copy. */
 int egr_denoise(egr_context *ctx, void *hip_stream);
 
 /* Multi-GPU image partition (not in the reference): this context only traces the 16x16-pixel
