@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
                                                        const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                                        const uint32_t *__restrict__ first, const uint32_t *__restrict__ last,
                                                        uint32_t *__restrict__ wide_of, uint32_t *__restrict__ counters, // [0] = #wide nodes, [1] = next frontier size
-                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes) {
+                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes, int absorb) {
     uint32_t t = blockIdx.x * BS + threadIdx.x;
     if (t >= count) return;
     const int b = (int)frontier_in[t];
@@ -240,12 +240,18 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
     child[0] = left[b], child[1] = right[b];
     auto leaves_of = [&](int id) -> uint32_t { return id >= n - 1 ? 1u : last[id] - first[id] + 1u; };
     while (nchild < EGR_WIDTH) {
-        int best = -1;
-        uint32_t best_leaves = 1;
+        // Which internal child to open: the largest one whose WHOLE subtree still fits into the free slots (it dissolves into
+        // this node instead of becoming an under-filled node of its own: fewer, fuller nodes = fewer 128-B node visits per
+        // ray); if none fits, the largest one (keeps the upper levels balanced).
+        const uint32_t free_slots = (uint32_t)(EGR_WIDTH - nchild);
+        int best = -1, fit = -1;
+        uint32_t best_leaves = 1, fit_leaves = 1;
         for (int k = 0; k < nchild; k++) {
             uint32_t l = leaves_of(child[k]);
             if (l > best_leaves) best_leaves = l, best = k;
+            if (absorb && l > fit_leaves && l - 1u <= free_slots) fit_leaves = l, fit = k;
         }
+        if (fit >= 0) best = fit;
         if (best < 0) break; // only leaves left
         const int id = child[best];
         child[best] = left[id]; // keep the Morton order of the children: insert the right child just after
@@ -444,7 +450,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->level_start = {0, 1};
         while (count > 0) {
             hipLaunchKernelGGL(k_collapse_level, dim3(nblk(count)), dim3(BS), 0, s, (int)n, count, fr0, c->k_left, c->k_right, c->k_first, c->k_last,
-                               c->wide_of, counters, fr1, c->wnodes);
+                               c->wide_of, counters, fr1, c->wnodes, c->collapse_absorb);
             uint32_t hc[2];
             EGR_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
             EGR_HIP(hipStreamSynchronize(s));
