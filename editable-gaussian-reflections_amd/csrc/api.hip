@@ -66,6 +66,7 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     if (const char *e = getenv("EGR_PACKET_MODE")) c->packet_mode = atoi(e);           // tuning knobs
     if (const char *e = getenv("EGR_BUCKETED_BACKWARD")) c->bucketed_backward = atoi(e);
     if (const char *e = getenv("EGR_MORTON_SIZE")) c->morton_size_period = atoi(e);
+    if (const char *e = getenv("EGR_BVH_BUILDER")) c->bvh_builder = atoi(e);
     if (const char *e = getenv("EGR_COLLAPSE_ABSORB")) c->collapse_absorb = atoi(e);
     if (const char *e = getenv("EGR_GROUP_WALK")) c->group_walk = atoi(e);
     if (const char *e = getenv("EGR_DENOISE")) c->denoise_mode = atoi(e);

@@ -276,6 +276,25 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
     }
 }
 
+// Alternative topology (EGR_BVH_BUILDER=1): a COMPLETE 8-ary tree over the Morton order - bottom nodes hold 8 consecutive sorted
+// gaussians, every upper node 8 consecutive nodes of the level below. All nodes but the last of a level are full (N/7 nodes
+// instead of ~N/5), at the price of groups that ignore the Morton prefix boundaries the Karras splits follow.
+// Level d (root = 0) has cnt[d] nodes starting at off[d]; the deepest level's slots are leaves.
+__global__ void __launch_bounds__(BS) k_implicit_level(uint32_t n, uint32_t off, uint32_t cnt, uint32_t child_off, uint32_t child_cnt, int bottom,
+                                                       uint4 *__restrict__ wnodes) {
+    const uint32_t t = blockIdx.x * BS + threadIdx.x; // one thread per child slot
+    const uint32_t i = t / EGR_WIDTH, k = t % EGR_WIDTH;
+    if (i >= cnt) return;
+    const uint32_t c = i * EGR_WIDTH + k;
+    uint32_t link = EGR_EMPTY_SLOT;
+    if (bottom) {
+        if (c < n) link = EGR_LEAF_FLAG | c;
+    } else if (c < child_cnt) {
+        link = child_off + c;
+    }
+    wnodes[(size_t)(off + i) * EGR_WIDTH + k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, link); // empty box until refit
+}
+
 // ---- 16-bit box quantisation in the build frame. u = (x - origin) * scale + 2 (cells); lo rounds down one extra
 // cell, hi up one extra cell; 0 / 65535 are the out-of-frame sentinels (decoded as -inf / +inf by the traversal).
 __device__ __forceinline__ uint32_t quant_lo(float x, float o, float s) {
@@ -436,6 +455,21 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         EGR_HIP(hipStreamSynchronize(s));
         c->num_wide = 1;
         c->level_start = {0, 1};
+    } else if (c->bvh_builder == 1) {
+        std::vector<uint32_t> cnt; // nodes per level, bottom first
+        for (uint32_t m = (n + EGR_WIDTH - 1) / EGR_WIDTH;; m = (m + EGR_WIDTH - 1) / EGR_WIDTH) {
+            cnt.push_back(m);
+            if (m == 1) break;
+        }
+        std::reverse(cnt.begin(), cnt.end()); // root first
+        c->level_start.assign(1, 0);
+        for (uint32_t m : cnt) c->level_start.push_back(c->level_start.back() + m);
+        for (size_t d = 0; d < cnt.size(); d++) {
+            const bool bottom = d + 1 == cnt.size();
+            hipLaunchKernelGGL(k_implicit_level, dim3(nblk((uint64_t)cnt[d] * EGR_WIDTH)), dim3(BS), 0, s, n, c->level_start[d], cnt[d],
+                               bottom ? 0u : c->level_start[d + 1], bottom ? 0u : cnt[d + 1], bottom ? 1 : 0, c->wnodes);
+        }
+        c->num_wide = c->level_start.back();
     } else {
         hipLaunchKernelGGL(k_karras, dim3(nblk(n - 1)), dim3(BS), 0, s, (int)n, c->keys_out, c->k_left, c->k_right, c->k_parent, c->k_first,
                            c->k_last);

@@ -159,6 +159,7 @@ struct egr_context {
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
     int bucketed_backward = 1;
     int group_walk = 1;
+    int bvh_builder = 0;          // 0: Karras binary LBVH collapsed to 8-wide, 1: complete 8-ary tree over the Morton order
     int collapse_absorb = 1;      // wide-BVH collapse: dissolve small subtrees into their parent node (see k_collapse_level)
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final
     float *denoise_tmp = nullptr; // two W*H*3 ping-pong images, allocated on first use
