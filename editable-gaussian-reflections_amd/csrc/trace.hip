@@ -315,14 +315,18 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                               w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
             const f3 ld = mk3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z,
                               w2.x * d.x + w2.y * d.y + w2.z * d.z);
-            if (!hits_unit_cube(lo, ld, near_plane, far_plane)) return 0;
             f3 dhat, u;
             closest_point(lo, ld, dhat, t, u);              // :41-45
             // each candidate is owned by exactly one of the three walked segments (see below): counted / accepted once
             if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return 0;
+            // OptiX only invokes the intersection program when the instance's unit cube overlaps [tmin,tmax]. A response point
+            // inside the unit sphere AND on the segment (segment 0) is itself a point of cube and segment, so the cube test is
+            // implied there; it is evaluated for everything else (it decides whether the candidate is counted).
+            const bool behind = dot(lo, ld) > 0.0f, outside = dot(u, u) > 1.0f;
+            if ((seg != 0 || behind || outside) && !hits_unit_cube(lo, ld, near_plane, far_plane)) return 0;
             // counted here: shaders.cu:33 (evaluations that reached the intersection program)
-            if (dot(lo, ld) > 0.0f) return 1;               // :36
-            if (dot(u, u) > 1.0f) return 1;                 // :48-51
+            if (behind) return 1;                           // :36
+            if (outside) return 1;                          // :48-51
             if (step != 0 && t < backfacing_max_dist) {     // :54-61 (world normal . object dir)
                 const float4 n0 = app[2 * prim], n1 = app[2 * prim + 1]; // raw normal, record order (k_live)
                 f3 gn = mk3(n0.w, n1.x, n1.y);
