@@ -71,10 +71,6 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     if (const char *e = getenv("EGR_GROUP_WALK")) c->group_walk = atoi(e);
     if (const char *e = getenv("EGR_DENOISE")) c->denoise_mode = atoi(e);
     if (const char *e = getenv("EGR_STRANDS")) c->strands = std::max(1, std::min(4, atoi(e)));
-    if (const char *e = getenv("EGR_GROUP_LANES")) {
-        int g = atoi(e);
-        if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) c->group_lanes = (uint32_t)g;
-    }
     if (const char *e = getenv("EGR_PACKET_COS_MIN")) c->packet_cos_min = (float)atof(e);
     if (const char *e = getenv("EGR_PACKET_ORIGIN_MAX")) c->packet_origin_max = (float)atof(e);
     int rc = guarded(c, [&] {

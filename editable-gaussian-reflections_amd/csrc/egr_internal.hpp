@@ -91,11 +91,9 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t *queues;      // [strands][6 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
     int group_walk;        // 1: incoherent tiles walk with 8 lanes per ray (see k_forward), 0: one lane per ray
-    uint32_t group_lanes;  // lanes that walk the tree in lockstep on the non-packet path (power of two, 1..64)
 };
 
 enum ControlWord : int {
-    CW_QUEUE0 = 0,      // task queue heads, one per step kernel (forward 0..2, backward 3..5)
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
     CW_BUCKET_RECORDS = 7, // records summed by k_bucket_reduce in this launch
@@ -107,7 +105,6 @@ enum ControlWord : int {
     CW_LIFE_LAUNCHES = 30,
     CW_DBG = 32,        // optional traversal statistics (EGR_TRAVERSAL_STATS builds): 8 x 64-bit
     CW_DBG2 = 48,       // per-phase s_memtime sums: [primary traversal, primary composite, bounce traversal, bounce composite]
-    CW_XQ = 64,         // XCD-affine task queues: [kernel 0..5][xcd 0..7] heads
     CW_DBG3 = 112,      // per forward step: min / max wave exit time (s_memrealtime)
     CW_COUNT = 128
 };
@@ -188,7 +185,6 @@ struct egr_context {
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
     int packet_mode = 1;
-    uint32_t group_lanes = 1;
     float packet_cos_min = 0.98f, packet_origin_max = 0.25f;
     std::string last_error;
 };

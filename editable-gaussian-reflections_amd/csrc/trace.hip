@@ -1410,7 +1410,6 @@ DeviceView egr_make_view(const egr_context *c) {
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
-    v.group_lanes = c->group_lanes;
     v.group_walk = c->group_walk;
     v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
     return v;
