@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--cpu-sample", default="480x270")
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
     p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default, 2); the per-kernel profile pass always uses 1")
+    p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
     p.add_argument("--forward-only", action="store_true", help="config B: no-grad render instead of a training iteration")
     return p.parse_args()
 
@@ -93,6 +94,9 @@ def main():
     m.get_config().num_bounces.fill_(a.bounces)
     if a.strands > 0:
         m.set_strands(a.strands)
+    if a.emulate_world > 1:
+        assert world == 1
+        m.set_partition(0, a.emulate_world)
     images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()}
     camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **images)
 

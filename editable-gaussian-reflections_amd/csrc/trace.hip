@@ -25,6 +25,10 @@
 
 #include "egr_state.hpp"
 
+#ifndef EGR_GPOP
+#define EGR_GPOP 4 // nodes a lane group pops per iteration of the group walk
+#endif
+
 namespace {
 
 // XCD-affine persistent scheduling: the task range is cut into 8 contiguous chunks (contiguous image bands), one
@@ -465,7 +469,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 f3 ginv = mk3(0, 0, 0), gnc = mk3(0, 0, 0);
                 uint32_t *__restrict__ queue_j = v.cand_queue;
                 for (;;) {
-                    if ((sp == 0u || nq + 2u * EGR_WIDTH > v.cand_cap) && !done) { // group-uniform: close (finished or queue full), open the next
+                    if ((sp == 0u || nq + (uint32_t)EGR_GPOP * EGR_WIDTH > v.cand_cap) && !done) { // group-uniform: close (finished or queue full), open the next
                         if (r != 0xFFFFFFFFu && m == 0u) gq[j] = nq, gsp[j] = sp;
                         bool found = false;
                         while (++r < 8u) {
@@ -485,21 +489,28 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                     }
                     if (__ballot(!done) == 0ull) break;
                     if (!done) {
-                        // pop up to two nodes: two independent line fetches in flight per group
+                        // pop up to EGR_GPOP nodes: that many independent line fetches in flight per group (the order in which
+                        // subtrees are visited is irrelevant: every overlapping leaf is collected). A tile's critical path is its
+                        // groups' eight rays walked one after the other, so the fetches per iteration set the latency of a tile.
                         auto pop = [&]() {
                             sp--;
                             uint32_t w = lstk[min(sp, (uint32_t)EGR_LSTK - 1u)][j];
                             if (sp >= EGR_LSTK) w = *reinterpret_cast<const volatile uint32_t *>(gstk + (size_t)(sp - EGR_LSTK) * EGR_WAVE + j);
                             return w;
                         };
-                        const uint32_t wa = pop();
-                        const bool two = sp > 0u;
-                        const uint32_t wb = two ? pop() : wa;
-                        const uint4 sa = wnodes[(size_t)wa * EGR_WIDTH + m];
-                        uint4 sb = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, EGR_EMPTY_SLOT); // inverted box: never hit
-                        if (two) sb = wnodes[(size_t)wb * EGR_WIDTH + m];
+                        uint4 sl_[EGR_GPOP];
+                        uint32_t npop = 0;
+#pragma unroll
+                        for (int u = 0; u < EGR_GPOP; u++) {
+                            sl_[u] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, EGR_EMPTY_SLOT);
+                            if (sp > 0u) {
+                                const uint32_t w = pop();
+                                sl_[u] = wnodes[(size_t)w * EGR_WIDTH + m];
+                                npop++;
+                            }
+                        }
 #ifdef EGR_TRAVERSAL_STATS
-                        st_visits += (m == 0u) ? (two ? 2u : 1u) : 0u;
+                        st_visits += (m == 0u) ? npop : 0u;
                         if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
 #endif
                         auto process = [&](const uint4 &sl) {
@@ -524,8 +535,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                             }
                             nq = min(nq + (uint32_t)__popc(gl), v.cand_cap);
                         };
-                        process(sa);
-                        process(sb);
+#pragma unroll
+                        for (int u = 0; u < EGR_GPOP; u++) process(sl_[u]); // a slot that was not popped is an empty slot
                     }
                 }
             }
