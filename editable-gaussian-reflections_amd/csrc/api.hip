@@ -190,6 +190,7 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
         out->status = w[CW_STATUS];
         out->bvh_depth = c->max_depth;
         out->bucket_records = w[CW_BUCKET_RECORDS];
+        if (getenv("EGR_DEBUG_EXT")) fprintf(stderr, "[egr] extension blocks used %u of %u, cand_cap %u\n", w[CW_EXT_BUMP], c->ext_blocks_cap, c->cand_cap);
         if (getenv("EGR_PRINT_TRAVERSAL_STATS")) {
             for (int k = 0; k < 2; k++)
                 fprintf(stderr, "[egr stats %s] lane node visits %llu, lane leaf-box hits %llu, wave inner iterations %llu, wave outer rounds %llu\n", k ? "bounce" : "primary",

@@ -19,6 +19,8 @@
 #define EGR_BUCKET_SHIFT 8         // gradient buckets of 256 Morton-consecutive gaussians (bounce-step backward)
 #define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
 #define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
+#define EGR_EXT_BLOCK 16384u // entries of one candidate-list extension block
+#define EGR_EXT_NONE 0xFFFFFFFFu
 #define EGR_HIT_BLOCK_ROWS 8  // composited-hit arena block: 8 rows x 64 lanes x 16 B (+1 header row)
 #define EGR_MAX_DEPTH_BINS 256
 
@@ -75,6 +77,11 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t *cand_queue;  // [slots][cand_cap][64]  leaf record indices awaiting evaluation (per-lane walk)
     uint32_t *stack_spill; // [slots][EGR_GSTK][64] traversal stack entries beyond the LDS part
     uint32_t cand_cap;
+    // candidate lists longer than cand_cap continue in an extension block (one per ray, EGR_EXT_BLOCK entries, bump-allocated per
+    // launch): the reference's candidate pool is global, a single grazing ray may take thousands of entries
+    float *ext_keys;
+    float2 *ext_vals;
+    uint32_t ext_blocks_cap;
     uint32_t num_slots;    // resident waves
     float4 *hit_arena;     // blocks of (1 + EGR_HIT_BLOCK_ROWS) rows x 64 lanes
     uint32_t hit_blocks_cap;
@@ -97,6 +104,7 @@ enum ControlWord : int {
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
     CW_BUCKET_RECORDS = 7, // records summed by k_bucket_reduce in this launch
+    CW_EXT_BUMP = 6,       // candidate-list extension blocks handed out in this launch
     CW_RAYS = 10,       // per-step 64-bit counters (two words each): rays[3], candidates[3], composited[3]
     CW_CAND = 16,
     CW_COMP = 22,
@@ -159,6 +167,9 @@ struct egr_context {
     int bvh_builder = 0;          // 0: Karras binary LBVH collapsed to 8-wide, 1: complete 8-ary tree over the Morton order
     int collapse_absorb = 1;      // wide-BVH collapse: dissolve small subtrees into their parent node (see k_collapse_level)
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final
+    float *ext_keys = nullptr;    // candidate-list extension blocks (see DeviceView)
+    float2 *ext_vals = nullptr;
+    uint32_t ext_blocks_cap = 0;
     float *denoise_tmp = nullptr; // two W*H*3 ping-pong images, allocated on first use
     int morton_size_period = 0; // 0: plain Morton order; k > 0: one size bit after every k xyz triples; < 0: size bit first (s x y z)
     // strands: the rank's tiles are cut into `strands` slices whose kernel sequences run on separate HIP streams, so one

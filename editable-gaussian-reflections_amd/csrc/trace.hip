@@ -238,6 +238,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     __shared__ uint32_t gsp[EGR_WAVE];            // group walk: stack height of a ray whose walk is not finished (0 = done)
     __shared__ uint32_t gcnt[EGR_WAVE], gtrav[EGR_WAVE]; // group walk: accepted / counted candidates per ray
     __shared__ float gT[EGR_WAVE];                // group walk: total transmittance per ray
+    __shared__ uint32_t gext[EGR_WAVE];           // group walk: extension block of a ray's candidate list (EGR_EXT_NONE: none)
     const float4 *__restrict__ app = v.app;
     const uint32_t END = v.num_nodes;
 
@@ -300,6 +301,11 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                            -((ro.z - v.frame.oz) * v.frame.sz + 2.0f) * invq.z);
         uint32_t nq = 0;      // leaves queued for evaluation (per-lane walk)
         uint32_t cnt = 0, traversed = 0;
+        uint32_t ext = EGR_EXT_NONE; // this ray's extension block (lists longer than cand_cap)
+        auto ext_alloc = [&]() -> uint32_t { // one lane: take an extension block; EGR_EXT_NONE - 1 = none left
+            const uint32_t e = atomicAdd(v.control + CW_EXT_BUMP, 1u);
+            return e < v.ext_blocks_cap ? e : EGR_EXT_NONE - 1u;
+        };
         float full_T = 1.0f;
         bool overflow = false;
 #ifdef EGR_TRAVERSAL_STATS
@@ -354,7 +360,15 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 vals[cnt] = make_float2(alpha, u2f(prim));
                 cnt++;
             } else {
-                overflow = true;
+                if (ext == EGR_EXT_NONE) ext = ext_alloc();
+                const uint32_t e = cnt - v.cand_cap;
+                if (ext < EGR_EXT_NONE - 1u && e < EGR_EXT_BLOCK) {
+                    v.ext_keys[(size_t)ext * EGR_EXT_BLOCK + e] = t;
+                    v.ext_vals[(size_t)ext * EGR_EXT_BLOCK + e] = make_float2(alpha, u2f(prim));
+                    cnt++;
+                } else {
+                    overflow = true;
+                }
             }
         };
         // Tile coherence decides HOW the tree is walked. Coherent tiles (all primary tiles, mirror-like bounces) walk
@@ -389,7 +403,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         const bool group_walk = !packet && v.group_walk != 0;
         if (group_walk) { // publish the rays; per-ray results accumulate in LDS over the three segments
             rayt[0][lane] = ro.x, rayt[1][lane] = ro.y, rayt[2][lane] = ro.z, rayt[3][lane] = rd.x, rayt[4][lane] = rd.y, rayt[5][lane] = rd.z;
-            gcnt[lane] = 0u, gtrav[lane] = 0u, gT[lane] = 1.0f;
+            gcnt[lane] = 0u, gtrav[lane] = 0u, gT[lane] = 1.0f, gext[lane] = EGR_EXT_NONE;
         }
         seg_lo = near_plane, seg_hi = far_plane;
         for (seg = 0; seg < 3; seg++) {
@@ -545,7 +559,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             const unsigned long long tga1 = __builtin_amdgcn_s_memtime();
 #endif
             {   // ---------------- phase B
-                uint32_t r = 0xFFFFFFFFu, j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0;
+                uint32_t r = 0xFFFFFFFFu, j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0, extj = EGR_EXT_NONE;
                 bool done = false;
                 float Tpart = 1.0f;
                 f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
@@ -570,7 +584,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                             o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
                             queue_j = v.cand_queue + (scratch0 + j) * v.cand_cap;
                             keys_j = v.cand_keys + (scratch0 + j) * v.cand_cap, vals_j = v.cand_vals + (scratch0 + j) * v.cand_cap;
-                            nqj = gq[j], k0 = 0u, cntg = gcnt[j], travg = 0u, Tpart = 1.0f;
+                            nqj = gq[j], k0 = 0u, cntg = gcnt[j], travg = 0u, Tpart = 1.0f, extj = gext[j];
                         }
                     }
                     if (__ballot(!done) == 0ull) break;
@@ -590,13 +604,25 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
 #endif
                         const uint32_t gc = (uint32_t)(__ballot(res >= 1) >> g8) & 0xFFu, ga = (uint32_t)(__ballot(res == 2) >> g8) & 0xFFu;
+                        if (cntg + (uint32_t)__popc(ga) > v.cand_cap && extj == EGR_EXT_NONE) { // group-uniform: the list outgrows its run
+                            uint32_t e = EGR_EXT_NONE;
+                            if (m == 0u) e = ext_alloc(), gext[j] = e;
+                            extj = (uint32_t)__shfl((int)e, (int)g8); // from the group's lane 0 (an LDS round trip within one statement
+                                                                      // sequence is a data race the compiler may "optimise")
+                        }
                         if (res == 2) {
                             const uint32_t at = cntg + (uint32_t)__popc(ga & below);
-                            if (at < v.cand_cap) keys_j[at] = t, vals_j[at] = make_float2(alpha, u2f(pidx));
-                            else g_over = true;
+                            if (at < v.cand_cap) {
+                                keys_j[at] = t, vals_j[at] = make_float2(alpha, u2f(pidx));
+                            } else if (extj < EGR_EXT_NONE - 1u && at - v.cand_cap < EGR_EXT_BLOCK) {
+                                v.ext_keys[(size_t)extj * EGR_EXT_BLOCK + (at - v.cand_cap)] = t;
+                                v.ext_vals[(size_t)extj * EGR_EXT_BLOCK + (at - v.cand_cap)] = make_float2(alpha, u2f(pidx));
+                            } else {
+                                g_over = true;
+                            }
                             Tpart = (float)((double)Tpart * (1.0 - (double)alpha)); // :70 (Q1: over ALL accepted candidates)
                         }
-                        cntg = min(cntg + (uint32_t)__popc(ga), v.cand_cap);
+                        cntg = min(cntg + (uint32_t)__popc(ga), v.cand_cap + (extj < EGR_EXT_NONE - 1u ? EGR_EXT_BLOCK : 0u));
                         travg += (uint32_t)__popc(gc);
                         k0 += 8u;
                     }
@@ -692,7 +718,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
         }
 
         }
-        if (group_walk) cnt = gcnt[lane], traversed = gtrav[lane], full_T = gT[lane];
+        if (group_walk) cnt = gcnt[lane], traversed = gtrav[lane], full_T = gT[lane], ext = gext[lane];
 #ifdef EGR_TRAVERSAL_STATS
         const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
         {
@@ -735,13 +761,15 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         }
                     };
                     // two 16-B loads per 8 keys (cand_cap is a multiple of 8, so runs are 32-B aligned), in flight together
+                    const uint32_t nbase = min(cnt, v.cand_cap);
                     uint32_t k = 0;
-                    for (; k + 8 <= cnt; k += 8) {
+                    for (; k + 8 <= nbase; k += 8) {
                         const float4 ka = *reinterpret_cast<const float4 *>(keys + k), kb = *reinterpret_cast<const float4 *>(keys + k + 4);
                         consider(ka.x, k), consider(ka.y, k + 1), consider(ka.z, k + 2), consider(ka.w, k + 3);
                         consider(kb.x, k + 4), consider(kb.y, k + 5), consider(kb.z, k + 6), consider(kb.w, k + 7);
                     }
-                    for (; k < cnt; k++) consider(keys[k], k);
+                    for (; k < nbase; k++) consider(keys[k], k);
+                    for (; k < cnt; k++) consider(v.ext_keys[(size_t)ext * EGR_EXT_BLOCK + (k - v.cand_cap)], k); // the extension block (rare)
                     if (ki[0] == 0xFFFFFFFFu || !(kt[0] < far_plane)) running = false; // :81, :91-93
                 }
                 if (__ballot(running) == 0ull) break;
@@ -764,7 +792,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         const float best = kt[j];
                         t_prev = best;
                         k_prev = ki[j];
-                        float2 av = vals[ki[j]];
+                        float2 av = ki[j] < v.cand_cap ? vals[ki[j]] : v.ext_vals[(size_t)ext * EGR_EXT_BLOCK + (ki[j] - v.cand_cap)];
                         float alpha = av.x;
                         uint32_t pos = f2u(av.y); // record index (sorted position)
                         float4 a0 = app[2 * pos], a1 = app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
@@ -1330,7 +1358,7 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp);
+    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
     for (int i = 0; i < 4; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -1362,6 +1390,10 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->cand_keys, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
     EGR_HIP(hipMalloc((void **)&c->cand_vals, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
     EGR_HIP(hipMalloc((void **)&c->cand_queue, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
+    // extension blocks: 1/8 of the forward byte budget on top (12 B per entry), at least 64 blocks
+    c->ext_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(fwd_bytes / 8.0 / (12.0 * EGR_EXT_BLOCK)), 64), 65536);
+    EGR_HIP(hipMalloc((void **)&c->ext_keys, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float)));
+    EGR_HIP(hipMalloc((void **)&c->ext_vals, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float2)));
     EGR_HIP(hipMalloc((void **)&c->stack_spill, S * c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
     double bwd_bytes = (double)c->bwd_capacity * 36.0;
     if (c->bucketed_backward) bwd_bytes *= 0.25; // the rest holds the gradient buckets
@@ -1418,6 +1450,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
+    v.ext_keys = c->ext_keys, v.ext_vals = c->ext_vals, v.ext_blocks_cap = c->ext_blocks_cap;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;

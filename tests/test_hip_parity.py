@@ -349,6 +349,35 @@ def test_capacity_overflow_is_flagged_not_silent(ren, orc, syn):
     assert status & 2, "hit-arena overflow must be reported"  # upstream writes out of bounds here (per_pixel_linked_list.h:30-42)
 
 
+def test_candidate_lists_longer_than_capacity_continue_in_extension_blocks(ren, orc, syn):
+    """ppll_forward_size so small that a ray's own run holds 64 candidates: longer lists spill into extension blocks (the
+    reference's pool is global: a single ray may use any number of entries) and the images / gradients still match."""
+    W, H = 96, 64
+    g = syn.make_scene(6000, "init", seed=3)  # opacity 0.1: long candidate lists
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0), fwd=1000, bwd=50_000_000)
+    with torch.no_grad():
+        rt(cam_obj(ren, cam))
+    c = rt.cuda_module.get_counters()
+    st = rt.cuda_module.get_stats()
+    assert c[11] == 0, "no overflow: the lists continue in extension blocks"
+    assert int(st.num_traversed_per_pixel.max().item()) > 150  # far more candidates on some rays than one 64-entry run holds
+    ref = o.raytrace(False)
+    out = hip_outputs(rt)
+    for k in ("output_rgb", "output_final", "output_total_transmittance"):
+        assert psnr(out[k], ref[k]) > 80, k
+    # gradients: identical (up to float-atomic order) to a run whose lists fit their own runs
+    big, _ = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0), fwd=50_000_000, bwd=50_000_000)
+    for r in (rt, big):
+        r.cuda_module.get_metadata().total_num_calls.zero_()
+        run_grad(ren, r, cam_obj(ren, cam, tg))
+        assert r.cuda_module.get_counters()[11] == 0
+    hs, hb = hip_grads(rt), hip_grads(big)
+    for k in GRAD_KEYS:
+        assert np.abs(hs[k] - hb[k]).max() / (np.abs(hb[k]).max() + 1e-30) < 1e-5, k
+
+
 def test_tile_partition_sums_to_full_image(ren, orc, syn):
     """Multi-GPU split on one device: rank r of 2 traces its tiles only; images tile together, gradients add up."""
     W, H = 80, 48
