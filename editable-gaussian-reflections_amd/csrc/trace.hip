@@ -405,12 +405,25 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             rayt[0][lane] = ro.x, rayt[1][lane] = ro.y, rayt[2][lane] = ro.z, rayt[3][lane] = rd.x, rayt[4][lane] = rd.y, rayt[5][lane] = rd.z;
             gcnt[lane] = 0u, gtrav[lane] = 0u, gT[lane] = 1.0f, gext[lane] = EGR_EXT_NONE;
         }
+        // Segment 2 (t > far) can only hold candidates if some box lies farther than the far plane: with every box inside the
+        // build frame (no sentinels) that needs a frame corner farther than `far` from the ray origin.
+        bool beyond_far_empty = false;
+        if (!sentinels) {
+            const float fx0 = v.frame.ox - 2.0f / v.frame.sx, fx1 = v.frame.ox + 65534.0f / v.frame.sx;
+            const float fy0 = v.frame.oy - 2.0f / v.frame.sy, fy1 = v.frame.oy + 65534.0f / v.frame.sy;
+            const float fz0 = v.frame.oz - 2.0f / v.frame.sz, fz1 = v.frame.oz + 65534.0f / v.frame.sz;
+            const float dx = fmaxf(fabsf(ro.x - fx0), fabsf(ro.x - fx1)), dy = fmaxf(fabsf(ro.y - fy0), fabsf(ro.y - fy1)),
+                        dz = fmaxf(fabsf(ro.z - fz0), fabsf(ro.z - fz1));
+            const bool reaches = !(dx * dx + dy * dy + dz * dz < far_plane * far_plane * 0.999f); // NaN-safe: unknown counts as "reaches"
+            beyond_far_empty = __ballot(ray_ok && reaches) == 0ull;
+        }
         seg_lo = near_plane, seg_hi = far_plane;
         for (seg = 0; seg < 3; seg++) {
             if (seg == 1) {
                 if (!(near_plane > 0.0f)) continue; // bounce steps start at 0: nothing before the segment
                 seg_lo = 0.0f, seg_hi = near_plane;
             } else if (seg == 2) {
+                if (beyond_far_empty) continue; // no box reaches past the far plane for any ray of this tile
                 seg_lo = far_plane, seg_hi = 3.0e38f;
             }
         if (packet) {
