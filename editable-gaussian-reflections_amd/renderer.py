@@ -82,26 +82,18 @@ class GaussianRaytracer:
     @torch.no_grad()
     def _export_param_values(self):  # gaussian_raytracer.py:41-50 (same order)
         g = self.cuda_module.get_gaussians()
-        g.scale.copy_(self.pc._get_scaling)
-        g.rotation.copy_(self.pc._get_rotation)
-        g.mean.copy_(self.pc.get_xyz)
-        g.opacity.copy_(self.pc._opacity)
-        g.rgb.copy_(self.pc.get_diffuse)
-        g.normal.copy_(self.pc.get_normal)
-        g.roughness.copy_(self.pc.get_roughness)
-        g.f0.copy_(self.pc.get_f0)
+        # the eight copy_ calls upstream, as one multi-tensor launch (same order, same semantics)
+        torch._foreach_copy_([g.scale, g.rotation, g.mean, g.opacity, g.rgb, g.normal, g.roughness, g.f0],
+                             [self.pc._get_scaling, self.pc._get_rotation, self.pc.get_xyz, self.pc._opacity, self.pc.get_diffuse, self.pc.get_normal,
+                              self.pc.get_roughness, self.pc.get_f0])
 
     @torch.no_grad()
     def _import_param_gradients(self):  # gaussian_raytracer.py:53-62
         g = self.cuda_module.get_gaussians()
-        self.pc._xyz.grad.add_(g.mean.grad)
-        self.pc._opacity.grad.add_(g.opacity.grad)
-        self.pc._scaling.grad.add_(g.scale.grad)
-        self.pc._rotation.grad.add_(g.rotation.grad)
-        self.pc._diffuse.grad.add_(g.rgb.grad)
-        self.pc._normal.grad.add_(g.normal.grad)
-        self.pc._roughness.grad.add_(g.roughness.grad)
-        self.pc._f0.grad.add_(g.f0.grad)
+        # the eight add_ calls upstream, as one multi-tensor launch
+        torch._foreach_add_([self.pc._xyz.grad, self.pc._opacity.grad, self.pc._scaling.grad, self.pc._rotation.grad, self.pc._diffuse.grad,
+                             self.pc._normal.grad, self.pc._roughness.grad, self.pc._f0.grad],
+                            [g.mean.grad, g.opacity.grad, g.scale.grad, g.rotation.grad, g.rgb.grad, g.normal.grad, g.roughness.grad, g.f0.grad])
 
     def zero_grad(self):  # gaussian_raytracer.py:64-73 (one fill of the flat buffer == the eight zero_() upstream + total_weight kept)
         g = self.cuda_module.get_gaussians()
