@@ -240,13 +240,15 @@ def test_grad_mode_writes_no_images_and_accumulates_grads(ren, orc, syn):
 
 
 # ------------------------------------------------------------------------------------------------ semantics
-def test_update_bvh_snapshot_semantics(ren, orc, syn):
+@pytest.mark.parametrize("bounces", [0, 2])
+def test_update_bvh_snapshot_semantics(ren, orc, syn, bounces):
     """No-grad renders do not refresh the transforms (gaussian_raytracer.py:139): traversal uses the snapshot while
-    alpha / sigma / appearance read the live tensors."""
+    alpha / sigma / appearance read the live tensors. The 0.3 shift also pushes boxes out of the build
+    frame (5 % head-room), so the refit part runs the walks' out-of-frame (sentinel) decode - packet and group walk."""
     W, H = 48, 32
     g = syn.make_scene(2000, "trained", seed=9)
     cam = syn.default_camera()
-    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=0))
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=bounces))
     g2 = {k: v.copy() for k, v in g.items()}
     g2["mean"] += 0.3  # moved geometry ...
     g2["rgb"] = 1.0 - g2["rgb"]  # ... and recoloured
@@ -262,6 +264,7 @@ def test_update_bvh_snapshot_semantics(ren, orc, syn):
     o.update_bvh()
     ref2 = o.raytrace(False)
     assert psnr(hip_outputs(rt)["output_rgb"][0], ref2["output_rgb"][0]) > 60
+    assert psnr(hip_outputs(rt)["output_final"], ref2["output_final"]) > 55  # bounce steps included
     assert psnr(ref["output_rgb"][0], ref2["output_rgb"][0]) < 40  # the two states really differ
 
 
