@@ -21,6 +21,8 @@ HIPCC = os.environ.get("HIPCC", shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 if os.environ.get("EGR_GPOP"):
     HIP_FLAGS.append("-DEGR_GPOP=" + os.environ["EGR_GPOP"])
+if os.environ.get("EGR_DEBUG_LIST"):
+    HIP_FLAGS.append("-DEGR_DEBUG_LIST=1")
 if os.environ.get("EGR_TRAVERSAL_STATS"):
     HIP_FLAGS.append("-DEGR_TRAVERSAL_STATS=1")
 HIP_SOURCES = ["trace.hip", "epilogue.hip", "bvh.hip", "api.hip", "knn.hip", "step.hip", "denoise.hip"]

@@ -732,6 +732,16 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 
         }
         if (group_walk) cnt = gcnt[lane], traversed = gtrav[lane], full_T = gT[lane], ext = gext[lane];
+#ifdef EGR_DEBUG_LIST
+        if (active && cnt > 0 && cnt <= v.cand_cap) {
+            double p = 1.0;
+            for (uint32_t k = 0; k < cnt; k++) p *= 1.0 - (double)vals[k].x;
+            if (fabs(p - (double)full_T) > 1e-4 * fmax(p, (double)full_T) + 1e-12) {
+                printf("[list mismatch] step %d task %u lane %d cnt %u prodlist %.9g full_T %.9g group %d\n", step, task, lane, cnt, p, (double)full_T, (int)group_walk);
+                for (uint32_t k = 0; k < cnt && k < 40; k++) printf("   k %u t %.9g alpha %.9g pos %u\n", k, (double)keys[k], (double)vals[k].x, f2u(vals[k].y));
+            }
+        }
+#endif
 #ifdef EGR_TRAVERSAL_STATS
         const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
         {
@@ -763,9 +773,11 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                         if (after && tk < kt[7]) { // displaces the current 8th: bubble into place (stable: equal t keeps list order)
                             float xt = tk;
                             uint32_t xi = k;
-#pragma unroll
+                            bool shifting = false; // once the new key has found its place everything behind it moves one slot to the right
+#pragma unroll                                     // (comparing the carried element with '<' again would put it BEHIND an equal key)
                             for (int j = 0; j < 8; j++) {
-                                const bool sw = xt < kt[j];
+                                const bool sw = shifting || xt < kt[j];
+                                shifting = sw;
                                 const float ot = kt[j];
                                 const uint32_t oi = ki[j];
                                 kt[j] = sw ? xt : ot, ki[j] = sw ? xi : oi;
