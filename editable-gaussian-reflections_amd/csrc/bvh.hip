@@ -34,7 +34,7 @@ inline int nblk(uint64_t n, int bs = BS) { return (int)((n + bs - 1) / bs); }
 // ---------------------------------------------------------------------------------------------------------
 // K1: per-Gaussian instance record. M = [R diag(exp(s) * sigma * g) | mean], W = M^-1 (analytic).
 // mask (bvh_wrapper.cu:55): sigma > 0 && any(size > 0); masked-out instances get an empty box (lo > hi) and a W
-// record that can never pass the cube test (they are cluster members, so traversal may still look at them).
+// record that can never pass the cube test (they keep their leaf slot, so a walk may still look at them).
 // ---------------------------------------------------------------------------------------------------------
 // Records are stored at the gaussian's MORTON-SORTED position (pos_of_gid), i.e. in leaf order: rays that are close
 // in space then read neighbouring 48-B records (same / adjacent cache lines) instead of lines scattered over the
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(BS) k_inverse_perm(uint32_t n, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Karras 2012 topology over the clusters. Id space: internal i in [0,n-2] -> i, leaf j in [0,n-1] -> (n-1)+j.
+// Karras 2012 topology over the sorted gaussians. Id space: internal i in [0,n-2] -> i, leaf j in [0,n-1] -> (n-1)+j.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int kdelta(const uint64_t *__restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;

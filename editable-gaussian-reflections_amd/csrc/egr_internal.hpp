@@ -40,7 +40,7 @@ inline void egr_hip_check(hipError_t e, const char *what) {
 // app    : float4[2N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y)       32 B
 // wnodes : uint4[8*Nw]     8-wide BVH, one 128-B line per node; child slot (16 B):
 //          x = lo.x | lo.y<<16, y = lo.z | hi.x<<16, z = hi.y | hi.z<<16 (16-bit cells of the build frame), w = link
-// inst_w / inst_m / app are indexed by SORTED POSITION (Morton / leaf order), cluster j = positions [C*j, C*j+C);
+// inst_w / inst_m / app / grad_rows are indexed by SORTED POSITION (Morton / leaf order);
 // gid_of_pos / pos_of_gid map between sorted positions and the caller's gaussian ids
 
 struct BvhFrame { // quantisation frame of one build: cell = (x - o) * s + 2

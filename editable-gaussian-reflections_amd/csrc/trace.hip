@@ -372,7 +372,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             }
         };
         // Tile coherence decides HOW the tree is walked. Coherent tiles (all primary tiles, mirror-like bounces) walk
-        // it as ONE packet: the node index is wave-uniform, nodes / cluster members / transforms come through the
+        // it as ONE packet: the node index is wave-uniform, nodes / leaf transforms come through the
         // scalar cache (one request per wave instead of 64 divergent gathers), every lane tests its own ray and a node
         // is entered when ANY lane overlaps it. Incoherent tiles walk per lane.
         bool packet;
