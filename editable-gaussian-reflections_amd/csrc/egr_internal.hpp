@@ -36,7 +36,8 @@ inline void egr_hip_check(hipError_t e, const char *what) {
 // ---- per-Gaussian records (internal layout in HBM) -----------------------------------------------------
 // inst_w : float4[4N]   64-B test record: rows of W = M^-1 (world->object; snapshot at update/rebuild) + live
 //                       quarter (f0.z, roughness, opacity, sigma) written per launch: one candidate test = one 64-B sector
-// inst_m : float4[3N]   rows of M   (object->world),      snapshot at update/rebuild      48 B
+// inst_m : float4[4N]   64-B backward record: rows of M (object->world) with exp(scale) in .w, raw quaternion; snapshot
+// grad_rows: float[32N] gradient accumulation, one 128-B line per gaussian (22 components used), zero between launches
 // app    : float4[2N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y)       32 B
 // wnodes : uint4[8*Nw]     8-wide BVH, one 128-B line per node; child slot (16 B):
 //          x = lo.x | lo.y<<16, y = lo.z | hi.x<<16, z = hi.y | hi.z<<16 (16-bit cells of the build frame), w = link
