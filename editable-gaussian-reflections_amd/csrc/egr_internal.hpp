@@ -16,7 +16,7 @@
 #define EGR_LEAF_FLAG 0x80000000u  // child slot link: leaf -> EGR_LEAF_FLAG | record index, internal -> child node index
 #define EGR_EMPTY_SLOT 0xFFFFFFFFu // unused child slot (checked before the leaf flag)
 #define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
-#define EGR_BUCKET_SHIFT 8         // gradient buckets of 256 Morton-consecutive gaussians (bounce-step backward)
+#define EGR_BUCKET_SHIFT 9         // gradient buckets of 512 Morton-consecutive gaussians (bounce-step backward)
 #define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
 #define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
 #define EGR_EXT_BLOCK 16384u // entries of one candidate-list extension block

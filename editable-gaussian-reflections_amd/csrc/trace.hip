@@ -1193,10 +1193,10 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
 // (first version: 2.0 ms for 25 M records) is bound by the LDS atomic unit. This version counting-sorts the slice's record
 // indices by gaussian with ONE returning integer atomic per record, then thread t sums the records of gaussian t in
 // registers (no float atomics), and the totals leave through LDS so that the gradient rows are written coalesced.
-__global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
+__global__ void __launch_bounds__(1 << EGR_BUCKET_SHIFT) k_bucket_reduce(DeviceView v) {
     constexpr int BG = 1 << EGR_BUCKET_SHIFT;          // gaussians per bucket (= threads per workgroup)
-    constexpr int PER = (int)(EGR_BUCKET_SLICE / 256u); // records per thread
-    static_assert(BG == 256, "one thread per gaussian of the bucket");
+    constexpr int PER = (int)(EGR_BUCKET_SLICE / (uint32_t)BG); // records per thread
+    static_assert(BG <= 1024 && EGR_BUCKET_SLICE % BG == 0, "one thread per gaussian of the bucket");
     __shared__ uint32_t hist[BG], start[BG];
     __shared__ uint16_t order[EGR_BUCKET_SLICE];
     __shared__ float acc[BG * 17]; // [gaussian][15 components], row padded to 17 words
@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
     uint32_t key[PER], rank[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const uint32_t r = (uint32_t)tid + 256u * (uint32_t)k;
+        const uint32_t r = (uint32_t)tid + (uint32_t)BG * (uint32_t)k;
         key[k] = r < n ? (f2u(reinterpret_cast<const float *>(src + 4 * (size_t)r)[0]) & (uint32_t)(BG - 1)) : 0u;
         rank[k] = r < n ? atomicAdd(&hist[key[k]], 1u) : 0u;
     }
@@ -1236,7 +1236,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const uint32_t r = (uint32_t)tid + 256u * (uint32_t)k;
+        const uint32_t r = (uint32_t)tid + (uint32_t)BG * (uint32_t)k;
         if (r < n) order[start[key[k]] + rank[k]] = (uint16_t)r;
     }
     __syncthreads();
@@ -1253,7 +1253,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(DeviceView v) {
     for (int c = 0; c < 15; c++) acc[17 * tid + c] = s[c];
     __syncthreads();
     // 16 consecutive threads write the first 64 B of one gradient row: coalesced, no scatter over the gradient tensors
-    for (int i = tid; i < BG * 16; i += 256) {
+    for (int i = tid; i < BG * 16; i += BG) {
         const uint32_t l = (uint32_t)i >> 4, cidx = (uint32_t)i & 15u, pos = bucket * BG + l;
         if (cidx >= 15u || pos >= v.n) continue;
         const float x = acc[17 * l + cidx];
@@ -1544,7 +1544,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             if (v.gb_data && nbuckets) { // one reduce for both bounce steps of all strands
                 egr_stamp_begin(c, "backward_bucket_reduce", s);
                 const uint32_t slices = (v.gb_cap + EGR_BUCKET_SLICE - 1u) / EGR_BUCKET_SLICE;
-                hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(256), 0, s, v);
+                hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(1u << EGR_BUCKET_SHIFT), 0, s, v);
                 egr_stamp_end(c, s);
             }
             if (v.n) {
