@@ -1120,40 +1120,57 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
                     // :210-220 flush: into the LDS table when a slot is found within 8 probes, else straight to global
                     const float d_rot0 = dd * -qu.x * inv3 + dL_dr * inv1, d_rot1 = dd * -qu.y * inv3 + dL_dx * inv1;
                     const float d_rot2 = dd * -qu.z * inv3 + dL_dy * inv1, d_rot3 = dd * -qu.w * inv3 + dL_dz * inv1;
+                    float gx[EGR_GT_COMPS];
+                    gx[GC_OPA] = d_opacity, gx[GC_SCALE] = d_scale.x, gx[GC_SCALE + 1] = d_scale.y, gx[GC_SCALE + 2] = d_scale.z;
+                    gx[GC_MEAN] = d_mean.x, gx[GC_MEAN + 1] = d_mean.y, gx[GC_MEAN + 2] = d_mean.z;
+                    gx[GC_ROT] = d_rot0, gx[GC_ROT + 1] = d_rot1, gx[GC_ROT + 2] = d_rot2, gx[GC_ROT + 3] = d_rot3;
+                    gx[GC_RGB] = d_rgb.x, gx[GC_RGB + 1] = d_rgb.y, gx[GC_RGB + 2] = d_rgb.z, gx[GC_WEIGHT] = weight;
+                    gx[GC_NORMAL] = d_n.x, gx[GC_NORMAL + 1] = d_n.y, gx[GC_NORMAL + 2] = d_n.z;
+                    gx[GC_F0] = d_f0.x, gx[GC_F0 + 1] = d_f0.y, gx[GC_F0 + 2] = d_f0.z, gx[GC_ROUGH] = d_rough;
+                    bool mine = true; // this lane still owns a contribution
+                    if (step == 0) {
+                        // Primary tiles are coherent: the pixel to the right / below very often composites the SAME gaussian at the same
+                        // hit index. `ds_add_f32` retires about one lane per clock, so equal neighbours are summed in registers first
+                        // (two DPP levels: x neighbour, then y neighbour) and only the surviving lane touches the table.
+                        const unsigned long long em = __ballot(true);
+#define EGR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xF, 0xF, false)
+#define EGR_COMBINE(d, ctrl)                                                                                  \
+    {                                                                                                          \
+        const bool pact = ((em >> ((uint32_t)lane ^ (d))) & 1ull) != 0ull;                                     \
+        const uint32_t ppos = (uint32_t)EGR_DPP_I(pos, ctrl), pmine = (uint32_t)EGR_DPP_I(mine ? 1 : 0, ctrl); \
+        const bool same = pact && pmine != 0u && mine && ppos == pos;                                          \
+        const bool take = same && ((uint32_t)lane & (d)) == 0u;                                                \
+        _Pragma("unroll") for (int c = 0; c < EGR_GT_COMPS; c++) {                                             \
+            const float o = __int_as_float(EGR_DPP_I(__float_as_int(gx[c]), ctrl));                            \
+            gx[c] += take ? o : 0.0f;                                                                          \
+        }                                                                                                      \
+        if (same && !take) mine = false;                                                                       \
+    }
+                        EGR_COMBINE(1u, 0xB1)  // quad_perm [1,0,3,2]: lane ^ 1
+                        EGR_COMBINE(8u, 0x128) // row_ror 8: lane ^ 8
+#undef EGR_COMBINE
+#undef EGR_DPP_I
+                    }
                     uint32_t slot = (pos * 2654435761u) >> 25; // top 7 bits -> [0,128); keyed by record index
                     bool found = false;
 #pragma unroll 1
-                    for (int probe = 0; probe < 8; probe++) {
+                    for (int probe = 0; probe < (mine ? 8 : 0); probe++) {
                         const uint32_t old = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, pos);
                         if (old == EGR_GT_EMPTY || old == pos) { found = true; break; }
                         slot = (slot + 1) & (EGR_GT_SLOTS - 1);
                     }
                     if (found) {
                         new_slots += 1;
-#define EGR_TA(c, val) atomicAdd(&gt_vals[(c) * EGR_GT_SLOTS + slot], (val));
-                        EGR_TA(GC_OPA, d_opacity) EGR_TA(GC_SCALE, d_scale.x) EGR_TA(GC_SCALE + 1, d_scale.y) EGR_TA(GC_SCALE + 2, d_scale.z)
-                        EGR_TA(GC_MEAN, d_mean.x) EGR_TA(GC_MEAN + 1, d_mean.y) EGR_TA(GC_MEAN + 2, d_mean.z)
-                        EGR_TA(GC_ROT, d_rot0) EGR_TA(GC_ROT + 1, d_rot1) EGR_TA(GC_ROT + 2, d_rot2) EGR_TA(GC_ROT + 3, d_rot3)
-                        EGR_TA(GC_RGB, d_rgb.x) EGR_TA(GC_RGB + 1, d_rgb.y) EGR_TA(GC_RGB + 2, d_rgb.z)
-                        if (step == 0) {
-                            EGR_TA(GC_NORMAL, d_n.x) EGR_TA(GC_NORMAL + 1, d_n.y) EGR_TA(GC_NORMAL + 2, d_n.z)
-                            EGR_TA(GC_F0, d_f0.x) EGR_TA(GC_F0 + 1, d_f0.y) EGR_TA(GC_F0 + 2, d_f0.z) EGR_TA(GC_ROUGH, d_rough)
-                        }
-                        EGR_TA(GC_WEIGHT, weight)
-#undef EGR_TA
+#pragma unroll
+                        for (int c = 0; c < EGR_GT_COMPS; c++)
+                            if (step == 0 || c < GC_NORMAL) atomicAdd(&gt_vals[c * EGR_GT_SLOTS + slot], gx[c]);
+                    } else if (!mine) {
+                        // summed into a neighbour's contribution
                     } else if (!bucketed) { // no buckets (primary step, or disabled): atomics on the gaussian's gradient row
                         float *grow = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE;
-                        atomicAdd(grow + GC_OPA, d_opacity);
-                        atomicAdd(grow + GC_SCALE, d_scale.x), atomicAdd(grow + GC_SCALE + 1, d_scale.y), atomicAdd(grow + GC_SCALE + 2, d_scale.z);
-                        atomicAdd(grow + GC_MEAN, d_mean.x), atomicAdd(grow + GC_MEAN + 1, d_mean.y), atomicAdd(grow + GC_MEAN + 2, d_mean.z);
-                        atomicAdd(grow + GC_ROT, d_rot0), atomicAdd(grow + GC_ROT + 1, d_rot1), atomicAdd(grow + GC_ROT + 2, d_rot2), atomicAdd(grow + GC_ROT + 3, d_rot3);
-                        atomicAdd(grow + GC_RGB, d_rgb.x), atomicAdd(grow + GC_RGB + 1, d_rgb.y), atomicAdd(grow + GC_RGB + 2, d_rgb.z);
-                        if (step == 0) {
-                            atomicAdd(grow + GC_NORMAL, d_n.x), atomicAdd(grow + GC_NORMAL + 1, d_n.y), atomicAdd(grow + GC_NORMAL + 2, d_n.z);
-                            atomicAdd(grow + GC_F0, d_f0.x), atomicAdd(grow + GC_F0 + 1, d_f0.y), atomicAdd(grow + GC_F0 + 2, d_f0.z);
-                            atomicAdd(grow + GC_ROUGH, d_rough);
-                        }
-                        atomicAdd(grow + GC_WEIGHT, weight);
+#pragma unroll
+                        for (int c = 0; c < EGR_GT_COMPS; c++)
+                            if (step == 0 || c < GC_NORMAL) atomicAdd(grow + c, gx[c]);
                     } else {
                         direct = true, dpos = pos;
                         dg[GC_OPA] = d_opacity, dg[GC_SCALE] = d_scale.x, dg[GC_SCALE + 1] = d_scale.y, dg[GC_SCALE + 2] = d_scale.z;
