@@ -959,7 +959,10 @@ EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_ke
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward(DeviceView v, int step) {
+// PRIMARY = step 0 (22 gradient components, coherent tiles, no buckets); the bounce instantiation drops the normal / f0 /
+// roughness chains and their registers.
+template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward(DeviceView v, int step_arg) {
+    const int step = PRIMARY ? 0 : step_arg;
     const int lane = threadIdx.x;
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
     __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
@@ -972,7 +975,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
     if (step > num_bounces) return;
     const egr_gaussians &g = v.g;
     uint32_t cur_q = blockIdx.x & 7u;
-    const bool bucketed = step > 0 && v.gb_data != nullptr;
+    const bool bucketed = !PRIMARY && v.gb_data != nullptr;
 
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8 * (3 + step), v.task_count, cur_q);
@@ -996,7 +999,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
         if (nhits > 0) {
             const uint32_t pid = tg.pixel_id;
             const float third = 1.0f / 3.0f;
-            if (step == 0) {
+            if (PRIMARY) {
                 f3 o_rgb = S.ld3(SF(0, S_RGB)), o_n = S.ld3(SF(0, S_NORMAL)), o_f0 = S.ld3(SF(0, S_F0));
                 float o_depth = S.ld(SF(0, S_DEPTH)), o_rough = S.ld(SF(0, S_ROUGH));
                 const float *td = v.fb.target_diffuse + 3 * (size_t)pid, *tn = v.fb.target_normal + 3 * (size_t)pid,
@@ -1066,7 +1069,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
 
                     w_rgb = w_rgb + (g_rgb - prev_rgb) * transmittance; // :118-132
                     prev_rgb = g_rgb;
-                    if (step == 0) {
+                    if (PRIMARY) {
                         f3 g_n = mk3(a0.w, a1.x, a1.y), g_f0 = mk3(a1.z, a1.w, a2.x);
                         w_n = w_n + (g_n - prev_n) * transmittance;
                         prev_n = g_n;
@@ -1128,7 +1131,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
                     gx[GC_NORMAL] = d_n.x, gx[GC_NORMAL + 1] = d_n.y, gx[GC_NORMAL + 2] = d_n.z;
                     gx[GC_F0] = d_f0.x, gx[GC_F0 + 1] = d_f0.y, gx[GC_F0 + 2] = d_f0.z, gx[GC_ROUGH] = d_rough;
                     bool mine = true; // this lane still owns a contribution
-                    if (step == 0) {
+                    if (PRIMARY) {
                         // Primary tiles are coherent: the pixel to the right / below very often composites the SAME gaussian at the same
                         // hit index. `ds_add_f32` retires about one lane per clock, so equal neighbours are summed in registers first
                         // (two DPP levels: x neighbour, then y neighbour) and only the surviving lane touches the table.
@@ -1163,14 +1166,14 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
                         new_slots += 1;
 #pragma unroll
                         for (int c = 0; c < EGR_GT_COMPS; c++)
-                            if (step == 0 || c < GC_NORMAL) atomicAdd(&gt_vals[c * EGR_GT_SLOTS + slot], gx[c]);
+                            if (PRIMARY || c < GC_NORMAL) atomicAdd(&gt_vals[c * EGR_GT_SLOTS + slot], gx[c]);
                     } else if (!mine) {
                         // summed into a neighbour's contribution
                     } else if (!bucketed) { // no buckets (primary step, or disabled): atomics on the gaussian's gradient row
                         float *grow = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE;
 #pragma unroll
                         for (int c = 0; c < EGR_GT_COMPS; c++)
-                            if (step == 0 || c < GC_NORMAL) atomicAdd(grow + c, gx[c]);
+                            if (PRIMARY || c < GC_NORMAL) atomicAdd(grow + c, gx[c]);
                     } else {
                         direct = true, dpos = pos;
                         dg[GC_OPA] = d_opacity, dg[GC_SCALE] = d_scale.x, dg[GC_SCALE + 1] = d_scale.y, dg[GC_SCALE + 2] = d_scale.z;
@@ -1544,7 +1547,8 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             if (grads) {
                 for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
                     egr_stamp_begin(c, bn[step], ls);
-                    hipLaunchKernelGGL(k_backward, sgrid, block, 0, ls, w, step);
+                    if (step == 0) hipLaunchKernelGGL(k_backward<true>, sgrid, block, 0, ls, w, step);
+                    else hipLaunchKernelGGL(k_backward<false>, sgrid, block, 0, ls, w, step);
                     egr_stamp_end(c, ls);
                 }
             } else {
