@@ -920,39 +920,51 @@ EGR_DI uint32_t bucket_alloc_wave(const DeviceView &v, bool need, uint32_t bucke
     const uint32_t base = (uint32_t)__shfl((int)base_mine, (int)my_leader);
     return need ? base + my_rank : 0xFFFFFFFFu;
 }
-EGR_DI bool bucket_store(const DeviceView &v, uint32_t pos, uint32_t at, float d_opacity, f3 d_scale, f3 d_mean, float r0, float r1, float r2, float r3,
-                         f3 d_rgb, float weight) {
-    if (at >= v.gb_cap) return false; // bucket full: the caller falls back to atomics (correct, slower)
-    const uint32_t bucket = pos >> EGR_BUCKET_SHIFT;
-    float4 *dst = v.gb_data + ((size_t)bucket * v.gb_cap + at) * 4;
-    dst[0] = make_float4(u2f(pos & ((1u << EGR_BUCKET_SHIFT) - 1u)), d_opacity, d_scale.x, d_scale.y);
-    dst[1] = make_float4(d_scale.z, d_mean.x, d_mean.y, d_mean.z);
-    dst[2] = make_float4(r0, r1, r2, r3);
-    dst[3] = make_float4(d_rgb.x, d_rgb.y, d_rgb.z, weight);
-    return true;
+// Writes the records of the lanes with `ok` to their bucket slots, FOUR LANES PER RECORD: a lane stages its 64-B record in LDS,
+// then in each of four passes lane L stores quarter (L & 3) of the record of lane 16 * pass + (L >> 2) - one contiguous 64-B
+// request per record instead of four 16-B requests from one lane (the write-through L1 forwards every store instruction of a
+// lane as its own L2 request, and L2 requests are what bounds the bounce backward). Wave-uniform call; `stage` = 64 x 4 float4.
+EGR_DI void bucket_store_wave(const DeviceView &v, bool ok, uint32_t pos, uint32_t at, const float (&r)[15], float4 *stage) {
+    const int lane = threadIdx.x;
+    if (ok) {
+        stage[4 * lane + 0] = make_float4(u2f(pos & ((1u << EGR_BUCKET_SHIFT) - 1u)), r[GC_OPA], r[GC_SCALE], r[GC_SCALE + 1]);
+        stage[4 * lane + 1] = make_float4(r[GC_SCALE + 2], r[GC_MEAN], r[GC_MEAN + 1], r[GC_MEAN + 2]);
+        stage[4 * lane + 2] = make_float4(r[GC_ROT], r[GC_ROT + 1], r[GC_ROT + 2], r[GC_ROT + 3]);
+        stage[4 * lane + 3] = make_float4(r[GC_RGB], r[GC_RGB + 1], r[GC_RGB + 2], r[GC_WEIGHT]);
+    }
+    const uint32_t slot4 = ok ? ((pos >> EGR_BUCKET_SHIFT) * v.gb_cap + at) : 0xFFFFFFFFu; // record index in gb_data (x 4 float4)
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const int src = 16 * pass + (lane >> 2), q = lane & 3;
+        const uint32_t d = (uint32_t)__shfl((int)slot4, src);
+        if (d != 0xFFFFFFFFu) v.gb_data[(size_t)d * 4 + q] = stage[4 * src + q];
+    }
+    __syncthreads();
 }
 
-EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_keys, float *gt_vals, int lane) {
+template <int NC> EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane) {
     __syncthreads();
     for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: the bucket allocation below is a wave-level operation
         const int s = s0 + lane;
         const uint32_t pos = gt_keys[s];
         const bool valid = pos != EGR_GT_EMPTY;
         gt_keys[s] = EGR_GT_EMPTY;
-        float x[EGR_GT_COMPS];
+        float x[NC];
 #pragma unroll
-        for (int c = 0; c < EGR_GT_COMPS; c++) x[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f, gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
+        for (int c = 0; c < NC; c++) x[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f, gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
         bool stored = false;
-        if (bucketed && __ballot(valid) != 0ull) { // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
-            const uint32_t at = bucket_alloc_wave(v, valid, pos >> EGR_BUCKET_SHIFT);
-            if (valid)
-                stored = bucket_store(v, pos, at, x[GC_OPA], mk3(x[GC_SCALE], x[GC_SCALE + 1], x[GC_SCALE + 2]), mk3(x[GC_MEAN], x[GC_MEAN + 1], x[GC_MEAN + 2]),
-                                      x[GC_ROT], x[GC_ROT + 1], x[GC_ROT + 2], x[GC_ROT + 3], mk3(x[GC_RGB], x[GC_RGB + 1], x[GC_RGB + 2]), x[GC_WEIGHT]);
+        if constexpr (NC == 15) { // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
+            if (bucketed && __ballot(valid) != 0ull) {
+                const uint32_t at = bucket_alloc_wave(v, valid, pos >> EGR_BUCKET_SHIFT);
+                stored = valid && at < v.gb_cap; // bucket full: atomics below (correct, slower)
+                bucket_store_wave(v, stored, pos, at, x, stage);
+            }
         }
         if (valid && !stored) {
-            float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all 22 components of a gaussian share one line
+            float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all components of a gaussian share one line
 #pragma unroll
-            for (int c = 0; c < EGR_GT_COMPS; c++)
+            for (int c = 0; c < NC; c++)
                 if (x[c] != 0.0f) atomicAdd(row + c, x[c]);
         }
     }
@@ -964,10 +976,12 @@ EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_ke
 template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward(DeviceView v, int step_arg) {
     const int step = PRIMARY ? 0 : step_arg;
     const int lane = threadIdx.x;
+    constexpr int NC = PRIMARY ? EGR_GT_COMPS : (int)GC_NORMAL; // gradient components of this instantiation (22 / 15)
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
-    __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
+    __shared__ float gt_vals[NC * EGR_GT_SLOTS];
+    __shared__ float4 stage[PRIMARY ? 1 : 4 * EGR_WAVE]; // bucket records on their way out (bucket_store_wave)
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
-    for (int s = lane; s < EGR_GT_COMPS * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
+    for (int s = lane; s < NC * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
     __syncthreads();
     const float exp_power = *v.cfg.exp_power;
     const float eps_scale_grad = *v.cfg.eps_scale_grad;
@@ -1165,8 +1179,7 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
                     if (found) {
                         new_slots += 1;
 #pragma unroll
-                        for (int c = 0; c < EGR_GT_COMPS; c++)
-                            if (PRIMARY || c < GC_NORMAL) atomicAdd(&gt_vals[c * EGR_GT_SLOTS + slot], gx[c]);
+                        for (int c = 0; c < NC; c++) atomicAdd(&gt_vals[c * EGR_GT_SLOTS + slot], gx[c]);
                     } else if (!mine) {
                         // summed into a neighbour's contribution
                     } else if (!bucketed) { // no buckets (primary step, or disabled): atomics on the gaussian's gradient row
@@ -1182,14 +1195,12 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
                         dg[GC_RGB] = d_rgb.x, dg[GC_RGB + 1] = d_rgb.y, dg[GC_RGB + 2] = d_rgb.z, dg[GC_WEIGHT] = weight;
                     }
                 }
-                if (__ballot(direct) != 0ull) { // table full for these gaussians (bucketed steps only)
+                if (!PRIMARY && __ballot(direct) != 0ull) { // table full for these gaussians (bucketed steps only)
                     bool stored = false;
                     { // straight to the bucket (one counter atomic per distinct bucket of the wave)
                         const uint32_t at = bucket_alloc_wave(v, direct, dpos >> EGR_BUCKET_SHIFT);
-                        if (direct)
-                            stored = bucket_store(v, dpos, at, dg[GC_OPA], mk3(dg[GC_SCALE], dg[GC_SCALE + 1], dg[GC_SCALE + 2]),
-                                                  mk3(dg[GC_MEAN], dg[GC_MEAN + 1], dg[GC_MEAN + 2]), dg[GC_ROT], dg[GC_ROT + 1], dg[GC_ROT + 2], dg[GC_ROT + 3],
-                                                  mk3(dg[GC_RGB], dg[GC_RGB + 1], dg[GC_RGB + 2]), dg[GC_WEIGHT]);
+                        stored = direct && at < v.gb_cap; // bucket full: atomics below (correct, slower)
+                        bucket_store_wave(v, stored, dpos, at, dg, stage);
                     }
                     if (direct && !stored) {
                         float *grow = v.grad_rows + (size_t)dpos * EGR_ROW_STRIDE;
@@ -1201,7 +1212,7 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
             blk = f2u(rows[0].x); // header: previous (older) block of this task
         }
         (void)new_slots;
-        grad_table_flush(v, bucketed, gt_keys, gt_vals, lane); // one flush per tile
+        grad_table_flush<NC>(v, bucketed, gt_keys, gt_vals, stage, lane); // one flush per tile
     }
 }
 
