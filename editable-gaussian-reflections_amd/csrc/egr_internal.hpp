@@ -98,6 +98,9 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t task_begin, task_count; // this strand's slice of the rank's task order (see egr_trace_launch)
     uint32_t *queues;      // [strands][6 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
+    int log_mode;          // bounce-step records go to one launch-wide log instead of per-gaussian-block buckets
+    uint32_t log_cap;      // log mode: records per resident wave slot
+    uint32_t log_slot0;    // log mode: first wave slot of this strand
     int group_walk;        // 1: incoherent tiles walk with 8 lanes per ray (see k_forward), 0: one lane per ray
 };
 
@@ -163,7 +166,7 @@ struct egr_context {
     uint32_t *cand_queue = nullptr, *stack_spill = nullptr;
     float4 *gb_data = nullptr;
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
-    int bucketed_backward = 1;
+    int bucketed_backward = 2; // bounce-step backward: 0 atomics on the gradient rows, 1 per-block buckets + counting-sort reduce, 2 per-wave record logs + apply
     int group_walk = 1;
     int bvh_builder = 0;          // 0: Karras binary LBVH collapsed to 8-wide, 1: complete 8-ary tree over the Morton order
     int collapse_absorb = 1;      // wide-BVH collapse: dissolve small subtrees into their parent node (see k_collapse_level)
