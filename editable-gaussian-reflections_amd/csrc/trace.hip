@@ -1307,8 +1307,9 @@ __global__ void __launch_bounds__(1 << EGR_BUCKET_SHIFT) k_bucket_reduce(DeviceV
 // bounce backward 2.4 + 1.8 ms -> 1.3 + 1.4 ms) - and this kernel applies them: 16 lanes per record, ONE 64-B atomic request to
 // the gaussian's gradient row (1.4 ms for 25 M records, against 0.6 ms for the counting-sort reduce of the bucket mode).
 __global__ void __launch_bounds__(256) k_log_apply(DeviceView v) {
-    const uint32_t count = min(v.gb_count[blockIdx.x], v.log_cap); // blockIdx.x = wave slot (all strands)
-    const float *recs = reinterpret_cast<const float *>(v.gb_data) + (size_t)blockIdx.x * v.log_cap * 16;
+    const uint32_t slot = v.log_slot0 + blockIdx.x; // wave slot of this strand
+    const uint32_t count = min(v.gb_count[slot], v.log_cap);
+    const float *recs = reinterpret_cast<const float *>(v.gb_data) + (size_t)slot * v.log_cap * 16;
     if (threadIdx.x == 0 && count) atomicAdd(v.control + CW_BUCKET_RECORDS, count);
     for (uint32_t i = threadIdx.x; i < count * 16u; i += 256u) {
         const float x = recs[i];
@@ -1588,6 +1589,13 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
                     if (step == 0) hipLaunchKernelGGL(k_backward<true>, sgrid, block, 0, ls, w, step);
                     else hipLaunchKernelGGL(k_backward<false>, sgrid, block, 0, ls, w, step);
                     egr_stamp_end(c, ls);
+                    if (step == 1 && w.gb_data && nbuckets && w.log_mode) {
+                        // the strand's bounce records are complete: apply them now, on the strand's stream - the kernel is bound by
+                        // atomic requests, not by the CUs, and overlaps with the other strand's kernels
+                        egr_stamp_begin(c, "backward_bucket_reduce", ls);
+                        hipLaunchKernelGGL(k_log_apply, dim3(c->num_slots), dim3(256), 0, ls, w);
+                        egr_stamp_end(c, ls);
+                    }
                 }
             } else {
                 egr_stamp_begin(c, "write_outputs", ls);
@@ -1600,11 +1608,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             }
         }
         if (grads) {
-            if (v.gb_data && nbuckets && v.log_mode) {
-                egr_stamp_begin(c, "backward_bucket_reduce", s);
-                hipLaunchKernelGGL(k_log_apply, dim3(c->num_slots * (uint32_t)c->strands), dim3(256), 0, s, v);
-                egr_stamp_end(c, s);
-            } else if (v.gb_data && nbuckets) { // one reduce for both bounce steps of all strands
+            if (v.gb_data && nbuckets && !v.log_mode) { // one reduce for both bounce steps of all strands
                 egr_stamp_begin(c, "backward_bucket_reduce", s);
                 const uint32_t slices = (v.gb_cap + EGR_BUCKET_SLICE - 1u) / EGR_BUCKET_SLICE;
                 hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(1u << EGR_BUCKET_SHIFT), 0, s, v);
