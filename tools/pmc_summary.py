@@ -11,7 +11,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/pmc*/**/*counter_collection.csv", recu
         per.setdefault(key, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
     fwd = [v for (d, n), v in sorted(per.items()) if "k_forward" in n][-3:]
     bwd = [v for (d, n), v in sorted(per.items()) if "k_backward" in n][-3:]
-    red = [v for (d, n), v in sorted(per.items()) if "k_bucket_reduce" in n][-1:]
+    red = [v for (d, n), v in sorted(per.items()) if "k_bucket_reduce" in n or "k_log_apply" in n][-1:]
     names = [f"forward_step{i}" for i in range(len(fwd))] + [f"backward_step{2 - i}" for i in range(len(bwd))] + ["backward_bucket_reduce"] * len(red)
     for name, v in zip(names, fwd + bwd + red):
         out[name].update(v)
