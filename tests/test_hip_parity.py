@@ -448,6 +448,10 @@ def test_strands_do_not_change_results(ren, orc, syn):
     rt, _ = make_pair(ren, orc, g, cam, W, H)
     m = rt.cuda_module
     res = {}
+    try:
+        m.set_strands(2)
+    except RuntimeError:
+        pytest.skip("context created with EGR_STRANDS=1")
     for s in (1, 2):
         m.set_strands(s)
         m.get_metadata().total_num_calls.zero_()  # same jitter / GGX random stream for both launches
