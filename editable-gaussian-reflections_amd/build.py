@@ -21,6 +21,8 @@ HIPCC = os.environ.get("HIPCC", shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 if os.environ.get("EGR_GPOP"):
     HIP_FLAGS.append("-DEGR_GPOP=" + os.environ["EGR_GPOP"])
+if os.environ.get("EGR_TASK_TIMES"):  # diagnostic: per-task walk / composite time of one step in the stats images (tools/task_times.py)
+    HIP_FLAGS.append("-DEGR_TASK_TIMES=" + os.environ["EGR_TASK_TIMES"])
 if os.environ.get("EGR_DEBUG_LIST"):
     HIP_FLAGS.append("-DEGR_DEBUG_LIST=1")
 if os.environ.get("EGR_TRAVERSAL_STATS"):

@@ -239,6 +239,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     __shared__ uint32_t gcnt[EGR_WAVE], gtrav[EGR_WAVE]; // group walk: accepted / counted candidates per ray
     __shared__ float gT[EGR_WAVE];                // group walk: total transmittance per ray
     __shared__ uint32_t gext[EGR_WAVE];           // group walk: extension block of a ray's candidate list (EGR_EXT_NONE: none)
+    __shared__ uint32_t glist[EGR_WAVE];          // group walk: the rays a phase has to process, compacted
+    __shared__ uint32_t gnext[2];                 // group walk: next entry of glist to hand out (phase A, phase B)
     const float4 *__restrict__ app = v.app;
     const uint32_t END = v.num_nodes;
 
@@ -285,6 +287,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 
 #ifdef EGR_TRAVERSAL_STATS
         const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef EGR_TASK_TIMES
+        const unsigned long long tt0 = __builtin_amdgcn_s_memrealtime();
 #endif
         // ---- R2: traversal + candidate evaluation (shaders.cu:9-75) -------------------------------------
         // Two DECOUPLED per-lane loops instead of one "find a leaf, wait for the wave, evaluate" loop: with a
@@ -486,26 +491,34 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             // single grazing ray may overlap thousands of gaussians).
             for (;;) {
             gq[lane] = 0u;
+            uint32_t nlist;
+            {   // the unfinished rays, compacted: groups TAKE rays from this list as they become free (a static "group g walks
+                // rays 8g..8g+7" split leaves seven groups waiting for the one that drew the heavy rays)
+                const bool todo = gsp[lane] != 0u;
+                const unsigned long long tm = __ballot(todo);
+                if (todo) glist[__popcll(tm & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+                nlist = (uint32_t)__popcll(tm);
+                if (lane == 0) gnext[0] = 0u, gnext[1] = 0u;
+            }
             __syncthreads();
 #ifdef EGR_TRAVERSAL_STATS
             const unsigned long long tga0 = __builtin_amdgcn_s_memtime();
 #endif
             {   // ---------------- phase A
-                uint32_t r = 0xFFFFFFFFu, j = g8, sp = 0, nq = 0;
-                bool done = false;
+                uint32_t j = g8, sp = 0, nq = 0;
+                bool done = false, open = false;
                 f3 ginv = mk3(0, 0, 0), gnc = mk3(0, 0, 0);
                 uint32_t *__restrict__ queue_j = v.cand_queue;
                 for (;;) {
                     if ((sp == 0u || nq + (uint32_t)EGR_GPOP * EGR_WIDTH > v.cand_cap) && !done) { // group-uniform: close (finished or queue full), open the next
-                        if (r != 0xFFFFFFFFu && m == 0u) gq[j] = nq, gsp[j] = sp;
-                        bool found = false;
-                        while (++r < 8u) {
-                            j = g8 + r;
-                            if (gsp[j] != 0u) { found = true; break; } // unfinished ray
-                        }
-                        if (!found) {
-                            done = true;
+                        if (open && m == 0u) gq[j] = nq, gsp[j] = sp;
+                        uint32_t idx = 0u;
+                        if (m == 0u) idx = atomicAdd(&gnext[0], 1u);
+                        idx = (uint32_t)__shfl((int)idx, (int)g8);
+                        if (idx >= nlist) {
+                            done = true, open = false;
                         } else {
+                            j = glist[idx], open = true;
                             const f3 o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
                             ginv = mk3(1.0f / (d.x * v.frame.sx), 1.0f / (d.y * v.frame.sy), 1.0f / (d.z * v.frame.sz));
                             gnc = mk3(-((o.x - v.frame.ox) * v.frame.sx + 2.0f) * ginv.x, -((o.y - v.frame.oy) * v.frame.sy + 2.0f) * ginv.y,
@@ -571,9 +584,16 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #ifdef EGR_TRAVERSAL_STATS
             const unsigned long long tga1 = __builtin_amdgcn_s_memtime();
 #endif
+            {   // the rays with queued leaves, compacted (same hand-out as phase A)
+                const bool todo = gq[lane] != 0u;
+                const unsigned long long tm = __ballot(todo);
+                if (todo) glist[__popcll(tm & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+                nlist = (uint32_t)__popcll(tm);
+            }
+            __syncthreads();
             {   // ---------------- phase B
-                uint32_t r = 0xFFFFFFFFu, j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0, extj = EGR_EXT_NONE;
-                bool done = false;
+                uint32_t j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0, extj = EGR_EXT_NONE;
+                bool done = false, open = false;
                 float Tpart = 1.0f;
                 f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
                 const uint32_t *__restrict__ queue_j = v.cand_queue;
@@ -581,19 +601,18 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
                 float2 *__restrict__ vals_j = v.cand_vals;
                 for (;;) {
                     if (k0 >= nqj && !done) { // group-uniform: close the finished ray, open the next one with queued leaves
-                        if (r != 0xFFFFFFFFu) {
+                        if (open) {
                             float Tp = Tpart; // product of the eight lanes' partial products (deterministic order)
                             Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 1)), Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 2)), Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 4));
                             if (m == 0u) gcnt[j] = cntg, gtrav[j] += travg, gT[j] = (float)((double)gT[j] * (double)Tp);
                         }
-                        bool found = false;
-                        while (++r < 8u) {
-                            j = g8 + r;
-                            if (gq[j] != 0u) { found = true; break; }
-                        }
-                        if (!found) {
-                            done = true;
+                        uint32_t idx = 0u;
+                        if (m == 0u) idx = atomicAdd(&gnext[1], 1u);
+                        idx = (uint32_t)__shfl((int)idx, (int)g8);
+                        if (idx >= nlist) {
+                            done = true, open = false;
                         } else {
+                            j = glist[idx], open = true;
                             o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
                             queue_j = v.cand_queue + (scratch0 + j) * v.cand_cap;
                             keys_j = v.cand_keys + (scratch0 + j) * v.cand_cap, vals_j = v.cand_vals + (scratch0 + j) * v.cand_cap;
@@ -749,6 +768,9 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             if (lane == 0) add64(v.control, CW_DBG + 8 * (step > 0), a), add64(v.control, CW_DBG + 8 * (step > 0) + 2, b), add64(v.control, CW_DBG + 8 * (step > 0) + 4, c2), add64(v.control, CW_DBG + 8 * (step > 0) + 6, d);
         }
 #endif
+#ifdef EGR_TASK_TIMES
+        const unsigned long long tt1 = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- R3: depth-ordered compositing (forward_pass.cu:48-137) --------------------------------------
         f3 c_rgb = mk3(0, 0, 0), c_n = mk3(0, 0, 0), c_f0 = mk3(0, 0, 0);
         float c_rough = 0.0f, c_depth = 0.0f, T = 1.0f;
@@ -866,6 +888,12 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             if (step == 0) v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)traversed;
             else v.stats.num_traversed_per_pixel[tg.pixel_id] += (int32_t)traversed; // forward_pass.cu:46
         }
+#ifdef EGR_TASK_TIMES // diagnostic build: the tile's first pixel carries the task's walk / composite time (10 ns units) of one step
+        if (step == EGR_TASK_TIMES && lane == 0 && tg.inside) {
+            v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)(tt1 - tt0);
+            v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)(__builtin_amdgcn_s_memrealtime() - tt1);
+        }
+#endif
         w_rays += active ? 1u : 0u;
         w_cand += active ? traversed : 0u;
         w_comp += active ? nhits : 0u;
