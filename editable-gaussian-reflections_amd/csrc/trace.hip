@@ -234,7 +234,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     const uint4 *__restrict__ wnodes = v.wnodes;
     __shared__ uint32_t lstk[EGR_LSTK][EGR_WAVE]; // per-ray traversal stack (this workgroup is one wave)
     __shared__ float rayt[6][EGR_WAVE];           // group walk: every ray's origin / direction, readable by its lane group
-    __shared__ uint32_t gq[EGR_WAVE];             // group walk: leaves queued per ray (0 = nothing to evaluate)
+    __shared__ __attribute__((aligned(16))) uint32_t gq[EGR_WAVE];             // group walk: leaves queued per ray (0 = nothing to evaluate)
     __shared__ uint32_t gsp[EGR_WAVE];            // group walk: stack height of a ray whose walk is not finished (0 = done)
     __shared__ uint32_t gcnt[EGR_WAVE], gtrav[EGR_WAVE]; // group walk: accepted / counted candidates per ray
     __shared__ float gT[EGR_WAVE];                // group walk: total transmittance per ray
@@ -585,10 +585,19 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             const unsigned long long tga1 = __builtin_amdgcn_s_memtime();
 #endif
             {   // the rays with queued leaves, compacted (same hand-out as phase A)
-                const bool todo = gq[lane] != 0u;
-                const unsigned long long tm = __ballot(todo);
-                if (todo) glist[__popcll(tm & ((1ull << lane) - 1ull))] = (uint32_t)lane;
-                nlist = (uint32_t)__popcll(tm);
+                // longest queue first: a long ray taken last would leave the other groups idle while it is evaluated
+                const uint32_t myq = gq[lane];
+                uint32_t rank = 0u;
+#pragma unroll 1
+                for (int l = 0; l < EGR_WAVE; l += 4) {
+                    const uint4 q4 = *reinterpret_cast<const uint4 *>(&gq[l]);
+                    rank += (q4.x > myq || (q4.x == myq && l < lane)) ? 1u : 0u;
+                    rank += (q4.y > myq || (q4.y == myq && l + 1 < lane)) ? 1u : 0u;
+                    rank += (q4.z > myq || (q4.z == myq && l + 2 < lane)) ? 1u : 0u;
+                    rank += (q4.w > myq || (q4.w == myq && l + 3 < lane)) ? 1u : 0u;
+                }
+                if (myq != 0u) glist[rank] = (uint32_t)lane;
+                nlist = (uint32_t)__popcll(__ballot(myq != 0u));
             }
             __syncthreads();
             {   // ---------------- phase B
