@@ -1,35 +1,42 @@
-"""Diagnostic (needs a build with EGR_TASK_TIMES=<step>): distribution of per-task walk / composite time of one forward step."""
-import importlib, sys, os, torch
+"""Diagnostic (needs a build with EGR_TASK_TIMES=<step>): start / end time of every task of one forward step -> how full the
+wave slots are over the kernel's lifetime, and what a longest-first order of the same tasks would give."""
+import importlib, sys, os, torch, numpy as np, heapq
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic"); ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
 W, H, N = 1920, 1080, 1_000_000
-world = int(os.environ.get("EMU_WORLD", "8"))
+world = int(os.environ.get("EMU_WORLD", "1"))
 g = syn.make_scene(N, "trained", seed=0); cam = syn.default_camera(); pc = ren.GaussianParams(g)
 rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000); m = rt.cuda_module
 m.set_strands(1)
+m.get_config().num_bounces.fill_(int(os.environ["TT_STEP"]))  # the measured step must be the last one (later steps overwrite the stats)
 if world > 1: m.set_partition(0, world)
 camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"])
 for _ in range(20):
     with torch.no_grad(): rt(camera)
 torch.cuda.synchronize()
 st = m.get_stats()
-walk = st.num_traversed_per_pixel.view(H, W)[::8, ::8].float() * 0.01  # us
-comp = st.num_accumulated_per_pixel.view(H, W)[::8, ::8].float() * 0.01
-hc = st.num_traversed_per_pixel.view(H // 8, 8, W // 8, 8).clone()
-hc[:, 0, :, 0] = 0
-hmax = hc.amax(dim=(1, 3)).float(); hsum = hc.sum(dim=(1, 3)).float()
-own = walk > 0
-q = torch.tensor([0.5, 0.9, 0.99, 0.999], device=walk.device)
-def qs(x):
-    s = x.sort().values
-    return [round(float(v), 1) for v in s[(q * (s.numel() - 1)).long()]] + [round(float(s[-1]), 1)]
-print("tasks", int(own.sum()))
-print("walk us  q50/90/99/99.9/max", qs(walk[own]), "mean", float(walk[own].mean()))
-print("comp us  q50/90/99/99.9/max", qs(comp[own]), "mean", float(comp[own].mean()))
-tot = (walk + comp)[own]
-print("total us q50/90/99/99.9/max", qs(tot), "mean", float(tot.mean()))
-top = tot.topk(10).indices
-print("top-10 tasks: walk, comp, tile max Hc (all steps, 63 px), tile sum Hc")
-for i in top.tolist():
-    print("  ", round(float(walk[own][i]), 1), round(float(comp[own][i]), 1), float(hmax[own][i]), float(hsum[own][i]))
-print("all-tile Hc: mean of tile max", float(hmax[own].mean()), "mean of tile sum", float(hsum[own].mean()))
+t0 = st.num_traversed_per_pixel.view(H, W)[::8, ::8].cpu().numpy().astype(np.int64).ravel()
+t1 = st.num_accumulated_per_pixel.view(H, W)[::8, ::8].cpu().numpy().astype(np.int64).ravel()
+own = t1 > t0
+t0, t1 = t0[own], t1[own]
+base = t0.min()
+s, e = (t0 - base) * 0.01, (t1 - base) * 0.01  # us
+dur = e - s
+slots = int(m.get_counters()[10]) if False else 3072
+print("tasks", len(s), "kernel span us", e.max(), "sum of task times / 3072 slots", dur.sum() / slots, "max task", dur.max(), "mean", dur.mean())
+# occupancy over time
+for frac in (0.25, 0.5, 0.75, 0.9, 1.0):
+    T = e.max() * frac
+    print(f"  at {T:8.1f} us: running {int(((s <= T) & (e > T)).sum()):5d}  finished {int((e <= T).sum()):6d}")
+last_start = s.max()
+print("last task starts at", last_start, "-> tail", e.max() - last_start)
+def simulate(order):
+    h = [0.0] * slots
+    heapq.heapify(h)
+    end = 0.0
+    for i in order:
+        t = heapq.heappop(h)
+        heapq.heappush(h, t + dur[i]); end = max(end, t + dur[i])
+    return end
+print("list schedule, same durations: start order", simulate(np.argsort(s)), " longest first", simulate(np.argsort(-dur)), " shortest first", simulate(np.argsort(dur)))
+np.save(os.path.join(ROOT, "gpurun_out", f"task_times_w{world}.npy"), np.stack([s, e]))
