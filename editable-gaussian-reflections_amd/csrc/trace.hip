@@ -777,9 +777,6 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             if (lane == 0) add64(v.control, CW_DBG + 8 * (step > 0), a), add64(v.control, CW_DBG + 8 * (step > 0) + 2, b), add64(v.control, CW_DBG + 8 * (step > 0) + 4, c2), add64(v.control, CW_DBG + 8 * (step > 0) + 6, d);
         }
 #endif
-#ifdef EGR_TASK_TIMES
-        const unsigned long long tt1 = __builtin_amdgcn_s_memrealtime();
-#endif
         // ---- R3: depth-ordered compositing (forward_pass.cu:48-137) --------------------------------------
         f3 c_rgb = mk3(0, 0, 0), c_n = mk3(0, 0, 0), c_f0 = mk3(0, 0, 0);
         float c_rough = 0.0f, c_depth = 0.0f, T = 1.0f;
@@ -897,10 +894,10 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             if (step == 0) v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)traversed;
             else v.stats.num_traversed_per_pixel[tg.pixel_id] += (int32_t)traversed; // forward_pass.cu:46
         }
-#ifdef EGR_TASK_TIMES // diagnostic build: the tile's first pixel carries the task's walk / composite time (10 ns units) of one step
+#ifdef EGR_TASK_TIMES // diagnostic build: the tile's first pixel carries the task's start / end time of one step (which must be the last)
         if (step == EGR_TASK_TIMES && lane == 0 && tg.inside) {
-            v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)(tt1 - tt0);
-            v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)(__builtin_amdgcn_s_memrealtime() - tt1);
+            v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)(tt0 & 0x7FFFFFFFull); // start / end, 10 ns ticks
+            v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
         }
 #endif
         w_rays += active ? 1u : 0u;
