@@ -18,6 +18,7 @@
 #define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
 #define EGR_BUCKET_SHIFT 9         // gradient buckets of 512 Morton-consecutive gaussians (bounce-step backward)
 #define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
+#define EGR_MAX_STRANDS 4
 #define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
 #define EGR_EXT_BLOCK 16384u // entries of one candidate-list extension block
 #define EGR_EXT_NONE 0xFFFFFFFFu
@@ -102,6 +103,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t log_cap;      // log mode: records per resident wave slot
     uint32_t log_slot0;    // log mode: first wave slot of this strand
     int group_walk;        // 1: incoherent tiles walk with 8 lanes per ray (see k_forward), 0: one lane per ray
+    uint32_t split_mask;   // bit s: forward step s runs as quarter tiles (16 rays per wave), its arena chains are per quarter
 };
 
 enum ControlWord : int {
@@ -168,6 +170,8 @@ struct egr_context {
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
     int bucketed_backward = 2; // bounce-step backward: 0 atomics on the gradient rows, 1 per-block buckets + counting-sort reduce, 2 per-wave record logs + apply
     int group_walk = 1;
+    int split_mode = 0;       // quarter-tile bounce steps: 0 never (default: measured neutral), 1 always, -1 auto (few tiles per wave slot) (EGR_SPLIT)
+    double split_below = 2.0; // auto: split when a strand has fewer tiles than this many per wave slot (EGR_SPLIT_BELOW)
     int bvh_builder = 0;          // 0: Karras binary LBVH collapsed to 8-wide, 1: complete 8-ary tree over the Morton order
     int collapse_absorb = 1;      // wide-BVH collapse: dissolve small subtrees into their parent node (see k_collapse_level)
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final
@@ -180,8 +184,8 @@ struct egr_context {
     // slice's persistent-wave tail (few long tiles left) is filled by the other slice's next kernel
     int strands = 2;        // allocated (scratch, streams)
     int strands_active = 0; // used by the next launch (0 = all allocated)
-    hipStream_t strand_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t strand_stream[EGR_MAX_STRANDS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[EGR_MAX_STRANDS] = {};
     uint32_t *queues = nullptr;
     uint32_t cand_cap = 0, num_slots = 0;
     float4 *hit_arena = nullptr;

@@ -257,16 +257,24 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     uint32_t w_rays = 0, w_cand = 0, w_comp = 0;
     uint32_t cur_q = blockIdx.x & 7u;
 
+    // Quarter split (few tiles per rank, see egr_trace_launch): a wave takes 16 of a tile's 64 rays, so a heavy tile is four
+    // short tasks on four SIMDs instead of one long one. Everything per ray (state, lists, arena rows) keeps its place; the
+    // tile's arena chain becomes four chains (one per quarter, heads in task_last_block[..][quarter]).
+    const bool split = ((v.split_mask >> step) & 1u) != 0u;
+
     for (;;) {
-        const uint32_t tq = wave_next_task(v.queues + 8 * step, v.task_count, cur_q);
+        const uint32_t tq = wave_next_task(v.queues + 8 * step, split ? v.task_count * 4u : v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
-        const uint32_t task = v.task_begin + tq;
+        const uint32_t task = v.task_begin + (split ? tq >> 2 : tq);
+        const uint32_t quarter = split ? (tq & 3u) : 0u;
+        const bool mine = !split || ((uint32_t)lane >> 4) == quarter; // the lanes whose rays this wave traces
         const TaskGeom tg = task_geom(v, task, lane);
         StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
-        if (GRADS && lane == 0) v.task_last_block[(size_t)step * v.num_tasks + task] = 0xFFFFFFFFu; // nothing recorded yet
+        const size_t chain_head = ((size_t)step * v.num_tasks + task) * 4u + quarter;
+        if (GRADS && lane == 0) v.task_last_block[chain_head] = 0xFFFFFFFFu; // nothing recorded yet
 
         // ---- R1: ray for this step ----------------------------------------------------------------------
-        bool active = tg.inside;
+        bool active = tg.inside && mine;
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
         uint32_t seed = 0;
         if (step == 0) {
@@ -866,8 +874,8 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             }
             if (GRADS) {
                 // arena exhausted: forward results stay exact, backward skips this task (status flag is raised)
-                if (lane == 0) v.task_last_block[(size_t)step * v.num_tasks + task] = recording ? last_block : 0xFFFFFFFFu;
-                S.st(SF(step, S_NHITS), u2f(recording ? nhits : 0u));
+                if (lane == 0) v.task_last_block[chain_head] = recording ? last_block : 0xFFFFFFFFu;
+                if (mine) S.st(SF(step, S_NHITS), u2f(recording ? nhits : 0u));
             }
         }
         if (overflow && active) atomicOr(v.control + CW_STATUS, EGR_STATUS_CANDIDATE_OVERFLOW);
@@ -895,7 +903,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
             else v.stats.num_traversed_per_pixel[tg.pixel_id] += (int32_t)traversed; // forward_pass.cu:46
         }
 #ifdef EGR_TASK_TIMES // diagnostic build: the tile's first pixel carries the task's start / end time of one step (which must be the last)
-        if (step == EGR_TASK_TIMES && lane == 0 && tg.inside) {
+        if (step == EGR_TASK_TIMES && lane == 0 && tg.inside && mine) {
             v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)(tt0 & 0x7FFFFFFFull); // start / end, 10 ns ticks
             v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
         }
@@ -1035,14 +1043,23 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
         const uint32_t tq = wave_next_task(v.queues + 8 * (3 + step), v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
         const uint32_t task = v.task_begin + tq;
-        uint32_t blk = v.task_last_block[(size_t)step * v.num_tasks + task];
-        if (blk == 0xFFFFFFFFu) continue;
+        // the tile's arena chain, or its four quarter chains (forward ran this step split): every lane follows its own
+        const bool split = !PRIMARY && ((v.split_mask >> step) & 1u) != 0u;
+        uint32_t blk = v.task_last_block[((size_t)step * v.num_tasks + task) * 4u + (split ? (uint32_t)lane >> 4 : 0u)];
+        if (__ballot(blk != 0xFFFFFFFFu) == 0ull) continue;
         const TaskGeom tg = task_geom(v, task, lane);
         StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
         uint32_t steps_done = tg.inside ? f2u(S.ld(F_STEPS)) : 0u;
-        uint32_t nhits = (tg.inside && (uint32_t)step < steps_done) ? f2u(S.ld(SF(step, S_NHITS))) : 0u; // shaders.cu:157-158
+        uint32_t nhits = (tg.inside && (uint32_t)step < steps_done && blk != 0xFFFFFFFFu) ? f2u(S.ld(SF(step, S_NHITS))) : 0u; // shaders.cu:157-158
         const uint32_t max_hits = wave_max_u32(nhits);
         if (max_hits == 0) continue;
+        uint32_t chain_hits = max_hits; // hits of the longest ray recorded in this lane's chain
+        if (split) {
+            chain_hits = nhits;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) chain_hits = max(chain_hits, (uint32_t)__shfl_xor((int)chain_hits, off));
+        }
+        const uint32_t chain_blocks = (chain_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
 
         // ---- B1: output gradients (backward_pass.cu:80-108); constant along the ray ----------------------
         f3 dL_rgb = mk3(0, 0, 0), dL_n = mk3(0, 0, 0), dL_f0 = mk3(0, 0, 0);
@@ -1090,7 +1107,8 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
         const uint32_t nblocks = (max_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
         uint32_t new_slots = 0;
         for (uint32_t b = nblocks; b-- > 0;) {
-            const float4 *rows = v.hit_arena + (size_t)blk * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE;
+            const bool in_chain = b < chain_blocks; // this lane's chain has a block for batch b
+            const float4 *rows = v.hit_arena + (size_t)(in_chain ? blk : 0u) * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE;
             for (int row = EGR_HIT_BLOCK_ROWS - 1; row >= 0; row--) {
                 const uint32_t it = b * EGR_HIT_BLOCK_ROWS + (uint32_t)row;
                 if (it >= max_hits) continue;
@@ -1249,7 +1267,7 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
                     }
                 }
             }
-            blk = f2u(rows[0].x); // header: previous (older) block of this task
+            if (in_chain) blk = f2u(rows[0].x); // header: previous (older) block of this chain
         }
         (void)new_slots;
         grad_table_flush<NC>(v, bucketed, gt_keys, gt_vals, stage, lane, log_used); // one flush per tile
@@ -1473,7 +1491,7 @@ void egr_build_task_order(egr_context *c) {
 
 void egr_trace_free(egr_context *c) {
     dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         c->strand_stream[i] = nullptr, c->ev_join[i] = nullptr;
@@ -1514,7 +1532,7 @@ void egr_trace_alloc(egr_context *c) {
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
     EGR_HIP(hipMalloc((void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
-    EGR_HIP(hipMalloc((void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * 4 * sizeof(uint32_t)));
     c->state_stride = c->num_tasks_total * EGR_WAVE;
     EGR_HIP(hipMalloc((void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
     EGR_HIP(hipMemset(c->state, 0, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
@@ -1569,6 +1587,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
     v.group_walk = c->group_walk;
+    v.split_mask = 0u;
     v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
     v.log_mode = c->bucketed_backward == 2, v.log_slot0 = 0;
     v.log_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->gb_buckets_alloc * c->gb_cap / std::max<uint64_t>((uint64_t)c->num_slots * (uint64_t)c->strands, 1), 1u << 24);
@@ -1610,10 +1629,16 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             w.stack_spill += slot0 * EGR_GSTK * EGR_WAVE;
             w.log_slot0 = (uint32_t)slot0;
             const dim3 sgrid(std::max(1u, std::min(c->num_slots, w.task_count)));
+            // Few tiles per wave slot (a rank of a multi-GPU partition): the step time is the latency of the heaviest tiles, not
+            // the throughput of the chip. The bounce steps then run as quarter tiles (16 rays per wave, see k_forward).
+            const bool split = c->group_walk && (c->split_mode == 1 || (c->split_mode < 0 && (double)w.task_count < c->split_below * (double)c->num_slots));
+            w.split_mask = split ? 0x6u : 0u; // steps 1, 2
+            const dim3 qgrid(std::max(1u, std::min(c->num_slots, w.task_count * 4u)));
             for (int step = 0; step < EGR_NSTEPS; step++) {
                 egr_stamp_begin(c, fn[step], ls);
-                if (grads) hipLaunchKernelGGL(k_forward<true>, sgrid, block, 0, ls, w, step);
-                else hipLaunchKernelGGL(k_forward<false>, sgrid, block, 0, ls, w, step);
+                const dim3 fgrid = ((w.split_mask >> step) & 1u) ? qgrid : sgrid;
+                if (grads) hipLaunchKernelGGL(k_forward<true>, fgrid, block, 0, ls, w, step);
+                else hipLaunchKernelGGL(k_forward<false>, fgrid, block, 0, ls, w, step);
                 egr_launch_step_epilogue(w, step, grads, ls);
                 egr_stamp_end(c, ls);
             }

@@ -472,6 +472,36 @@ def test_strands_do_not_change_results(ren, orc, syn):
         m.set_strands(99)
 
 
+def test_quarter_tile_split_does_not_change_results(ren, orc, syn, monkeypatch):
+    """Bounce steps traced as quarter tiles (16 rays per wave, four arena chains per tile: what a rank with few tiles per
+    wave slot does, EGR_SPLIT) give bit-identical images and the same gradients as whole-tile tasks."""
+    W, H = 200, 136
+    g = syn.make_scene(20000, "trained", seed=4)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EGR_SPLIT", mode)
+        rt, _ = make_pair(ren, orc, g, cam, W, H, fwd=40_000_000, bwd=40_000_000)
+        m = rt.cuda_module
+        m.get_config().num_bounces.fill_(2)
+        with torch.no_grad():
+            rt(cam_obj(ren, cam))
+        img = hip_outputs(rt)
+        m.get_metadata().total_num_calls.zero_()
+        run_grad(ren, rt, cam_obj(ren, cam, tg))
+        c = m.get_counters()
+        assert c[11] == 0, "status"
+        res[mode] = (img, hip_grads(rt), list(c[:9]))
+        del rt
+    for k in OUT_KEYS:
+        assert np.array_equal(res["0"][0][k], res["1"][0][k]), k
+    assert res["0"][2] == res["1"][2]
+    assert res["0"][2][1] > 0 and res["0"][2][7] > 0  # bounce rays were traced and composited
+    for k in GRAD_KEYS:
+        assert np.abs(res["0"][1][k] - res["1"][1][k]).max() / (np.abs(res["0"][1][k]).max() + 1e-30) < 1e-4, k
+
+
 # ------------------------------------------------------------------------------------------------ full size
 def test_full_size_properties_1080p_1M(ren, orc, syn):
     """BASELINE config C (1080p, 1M Gaussians): size-independent properties instead of a full oracle run."""
