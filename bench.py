@@ -144,7 +144,7 @@ def main():
 
     cpu = None
     hc_ref_per_ray = None  # reference-defined candidates per ray (cube overlaps) measured by the oracle sample
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (the other ranks would sit in the next collective meanwhile)
         from oracle import oracle as orc
 
         cw, ch = (int(x) for x in a.cpu_sample.split("x"))
