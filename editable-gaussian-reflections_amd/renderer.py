@@ -97,8 +97,8 @@ class GaussianRaytracer:
 
     def zero_grad(self):  # gaussian_raytracer.py:64-73 (one fill of the flat buffer == the eight zero_() upstream + total_weight kept)
         g = self.cuda_module.get_gaussians()
-        for t in (g.rgb, g.opacity, g.scale, g.rotation, g.mean, g.normal, g.roughness, g.f0):
-            t.grad.zero_()
+        n = g.mean.shape[0]
+        g.grad_flat[: 21 * n].zero_()  # the eight gradient tensors are the first 21N floats of the flat buffer; total_weight is the tail
 
     @torch.no_grad()
     def all_reduce_grads(self):
