@@ -39,4 +39,5 @@ def simulate(order):
         heapq.heappush(h, t + dur[i]); end = max(end, t + dur[i])
     return end
 print("list schedule, same durations: start order", simulate(np.argsort(s)), " longest first", simulate(np.argsort(-dur)), " shortest first", simulate(np.argsort(dur)))
-np.save(os.path.join(ROOT, "gpurun_out", f"task_times_w{world}.npy"), np.stack([s, e]))
+full = np.zeros(own.shape, np.float64); full[own] = dur  # per tile, raster order (0 = not this rank's)
+np.save(os.path.join(ROOT, "gpurun_out", f"task_dur_w{world}_step{os.environ['TT_STEP']}.npy"), full)
