@@ -70,6 +70,8 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     if (const char *e = getenv("EGR_COLLAPSE_ABSORB")) c->collapse_absorb = atoi(e);
     if (const char *e = getenv("EGR_GROUP_WALK")) c->group_walk = atoi(e);
     if (const char *e = getenv("EGR_SPLIT")) c->split_mode = atoi(e);
+    if (const char *e = getenv("EGR_CHAIN")) c->chain_mode = atoi(e);
+    if (const char *e = getenv("EGR_CHAIN_BELOW")) c->chain_below = atof(e);
     if (const char *e = getenv("EGR_SPLIT_BELOW")) c->split_below = atof(e);
     if (const char *e = getenv("EGR_DENOISE")) c->denoise_mode = atoi(e);
     if (const char *e = getenv("EGR_STRANDS")) c->strands = std::max(1, std::min(EGR_MAX_STRANDS, atoi(e)));

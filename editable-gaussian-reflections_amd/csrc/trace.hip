@@ -23,7 +23,8 @@
 #include <utility>
 #include <vector>
 
-#include "egr_state.hpp"
+#define EGR_CONTRACT_AFTER_EPILOGUE
+#include "egr_epilogue.hpp" // (includes egr_state.hpp) the step epilogue, for the fused per-tile chain
 
 #ifndef EGR_GPOP
 #define EGR_GPOP 4 // nodes a lane group pops per iteration of the group walk
@@ -225,32 +226,7 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v) {
 // forward: one bounce step for every ray of this rank
 // ---------------------------------------------------------------------------------------------------------
 template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(DeviceView v, int step) {
-    const int lane = threadIdx.x;
-    // candidate scratch of this resident wave: every lane owns a CONTIGUOUS run of cand_cap entries ([lane][k]). Lanes append at
-    // their own pace, so a [k][lane] interleave never coalesces and every 4-B store dirties its own line (measured 4.4 KB
-    // written per ray); contiguous runs let the L2 merge 16 appends into one line.
-    float *__restrict__ keys = v.cand_keys + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
-    float2 *__restrict__ vals = v.cand_vals + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
-    const uint4 *__restrict__ wnodes = v.wnodes;
-    __shared__ uint32_t lstk[EGR_LSTK][EGR_WAVE]; // per-ray traversal stack (this workgroup is one wave)
-    __shared__ float rayt[6][EGR_WAVE];           // group walk: every ray's origin / direction, readable by its lane group
-    __shared__ __attribute__((aligned(16))) uint32_t gq[EGR_WAVE];             // group walk: leaves queued per ray (0 = nothing to evaluate)
-    __shared__ uint32_t gsp[EGR_WAVE];            // group walk: stack height of a ray whose walk is not finished (0 = done)
-    __shared__ uint32_t gcnt[EGR_WAVE], gtrav[EGR_WAVE]; // group walk: accepted / counted candidates per ray
-    __shared__ float gT[EGR_WAVE];                // group walk: total transmittance per ray
-    __shared__ uint32_t gext[EGR_WAVE];           // group walk: extension block of a ray's candidate list (EGR_EXT_NONE: none)
-    __shared__ uint32_t glist[EGR_WAVE];          // group walk: the rays a phase has to process, compacted
-    __shared__ uint32_t gnext[2];                 // group walk: next entry of glist to hand out (phase A, phase B)
-    const float4 *__restrict__ app = v.app;
-    const uint32_t END = v.num_nodes;
-
-    const bool sentinels = __builtin_amdgcn_readfirstlane((int)*v.out_of_frame) != 0;
-    const float exp_power = *v.cfg.exp_power;
-    const float transmittance_threshold = *v.cfg.transmittance_threshold;
-    const float backfacing_max_dist = *v.cfg.backfacing_max_dist;
-    const float backfacing_thr = *v.cfg.backfacing_invalid_normal_threshold;
-    const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
-    const float far_plane = *v.cam.zfar;
+#include "forward_decl.inc"
     const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
     if (step > num_bounces) return;
 
@@ -265,649 +241,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8 * step, split ? v.task_count * 4u : v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
-        const uint32_t task = v.task_begin + (split ? tq >> 2 : tq);
-        const uint32_t quarter = split ? (tq & 3u) : 0u;
-        const bool mine = !split || ((uint32_t)lane >> 4) == quarter; // the lanes whose rays this wave traces
-        const TaskGeom tg = task_geom(v, task, lane);
-        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
-        const size_t chain_head = ((size_t)step * v.num_tasks + task) * 4u + quarter;
-        if (GRADS && lane == 0) v.task_last_block[chain_head] = 0xFFFFFFFFu; // nothing recorded yet
-
-        // ---- R1: ray for this step ----------------------------------------------------------------------
-        bool active = tg.inside && mine;
-        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-        uint32_t seed = 0;
-        if (step == 0) {
-            if (active) {
-                seed = tea4(tg.pixel_id, (uint32_t)*v.meta.total_num_calls); // shaders.cu:88
-                ro = mk3(v.cam.origin[0], v.cam.origin[1], v.cam.origin[2]);
-                rd = primary_direction(v, tg.px, tg.py, *v.cfg.jitter_primary_rays != 0, seed);
-            }
-        } else {
-            active = active && S.ld(F_ALIVE) != 0.0f;
-            if (active) {
-                ro = S.ld3(F_RAY_O);
-                rd = S.ld3(F_RAY_D);
-                seed = f2u(S.ld(F_SEED));
-            }
-        }
-        if (__ballot(active) == 0ull) continue;
-
-#ifdef EGR_TRAVERSAL_STATS
-        const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef EGR_TASK_TIMES
-        const unsigned long long tt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        // ---- R2: traversal + candidate evaluation (shaders.cu:9-75) -------------------------------------
-        // Two DECOUPLED per-lane loops instead of one "find a leaf, wait for the wave, evaluate" loop: with a
-        // per-round rendezvous the wave pays max-over-lanes of every leaf search (measured 18 % / 11 % SIMT
-        // efficiency on primary / bounce rays). Phase A only walks the threaded tree and queues the leaf ids whose
-        // box the segment overlaps; phase B evaluates the queue. The queue lives in the lane's key column
-        // (ids are overwritten by keys, write index <= read index).
-        const bool ray_ok = active && finite3(ro) && finite3(rd); // NaN rays (ggx_brdf.h:163) hit nothing
-        const unsigned long long act_mask = __ballot(ray_ok);
-        // the ray in the quantisation frame of the tree: cell = (x - o) * s + 2, same t parametrisation.
-        // slab plane distance t = (cell - oq) / (d * s) is evaluated as fma(cell, invq, -oq * invq).
-        const f3 invq = mk3(1.0f / (rd.x * v.frame.sx), 1.0f / (rd.y * v.frame.sy), 1.0f / (rd.z * v.frame.sz));
-        const f3 ncq = mk3(-((ro.x - v.frame.ox) * v.frame.sx + 2.0f) * invq.x, -((ro.y - v.frame.oy) * v.frame.sy + 2.0f) * invq.y,
-                           -((ro.z - v.frame.oz) * v.frame.sz + 2.0f) * invq.z);
-        uint32_t nq = 0;      // leaves queued for evaluation (per-lane walk)
-        uint32_t cnt = 0, traversed = 0;
-        uint32_t ext = EGR_EXT_NONE; // this ray's extension block (lists longer than cand_cap)
-        auto ext_alloc = [&]() -> uint32_t { // one lane: take an extension block; EGR_EXT_NONE - 1 = none left
-            const uint32_t e = atomicAdd(v.control + CW_EXT_BUMP, 1u);
-            return e < v.ext_blocks_cap ? e : EGR_EXT_NONE - 1u;
-        };
-        float full_T = 1.0f;
-        bool overflow = false;
-#ifdef EGR_TRAVERSAL_STATS
-        uint32_t st_visits = 0, st_leafhits = 0, st_inner = 0, st_outer = 0;
-#endif
-        int seg = 0;                 // which of the three walked segments is active (see the walk below)
-        float seg_lo, seg_hi;
-        auto slab = [&](const uint4 &q, const f3 &iq, const f3 &nq_) { // wave-uniform choice of the decode
-            return sentinels ? qslab_hit(q, iq, nq_, seg_lo, seg_hi) : qslab_hit_inframe(q, iq, nq_, seg_lo, seg_hi);
-        };
-        // R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record.
-        // `prim` is the gaussian's SORTED POSITION (record index), not its id.
-        // returns 0: not counted, 1: counted (reached the reference's intersection program), 2: accepted (t, alpha valid)
-        auto test_candidate = [&](const f3 &o, const f3 &d, uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src, float &t,
-                                  float &alpha) -> int {
-            const f3 lo = mk3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
-                              w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
-            const f3 ld = mk3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z,
-                              w2.x * d.x + w2.y * d.y + w2.z * d.z);
-            f3 dhat, u;
-            closest_point(lo, ld, dhat, t, u);              // :41-45
-            // each candidate is owned by exactly one of the three walked segments (see below): counted / accepted once
-            if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return 0;
-            // OptiX only invokes the intersection program when the instance's unit cube overlaps [tmin,tmax]. A response point
-            // inside the unit sphere AND on the segment (segment 0) is itself a point of cube and segment, so the cube test is
-            // implied there; it is evaluated for everything else (it decides whether the candidate is counted).
-            const bool behind = dot(lo, ld) > 0.0f, outside = dot(u, u) > 1.0f;
-            if ((seg != 0 || behind || outside) && !hits_unit_cube(lo, ld, near_plane, far_plane)) return 0;
-            // counted here: shaders.cu:33 (evaluations that reached the intersection program)
-            if (behind) return 1;                           // :36
-            if (outside) return 1;                          // :48-51
-            if (step != 0 && t < backfacing_max_dist) {     // :54-61 (world normal . object dir)
-                const float4 n0 = app[2 * prim], n1 = app[2 * prim + 1]; // raw normal, record order (k_live)
-                f3 gn = mk3(n0.w, n1.x, n1.y);
-                if (length(gn) > backfacing_thr && dot(gn, dhat) > 0.0f) return 1;
-            }
-            const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
-            f3 x = u * a2.w;                                          // :64
-            float gaussval = eval_gaussian_sq(dot(x, x), exp_power);   // :65
-            alpha = EGR_MAX_ALPHA * gaussval * a2.z;                   // kernel.cu:14-16
-            return 2;
-        };
-        auto evaluate = [&](uint32_t prim, const float4 &w0, const float4 &w1, const float4 &w2, auto a2src) {
-            float t = 0.0f, alpha = 0.0f;
-            const int r = test_candidate(ro, rd, prim, w0, w1, w2, a2src, t, alpha);
-            if (r == 0) return;
-            traversed++;
-            if (r == 1) return;
-            full_T = (float)((double)full_T * (1.0 - (double)alpha)); // :70
-            if (cnt < v.cand_cap) {
-                keys[cnt] = t;
-                vals[cnt] = make_float2(alpha, u2f(prim));
-                cnt++;
-            } else {
-                if (ext == EGR_EXT_NONE) ext = ext_alloc();
-                const uint32_t e = cnt - v.cand_cap;
-                if (ext < EGR_EXT_NONE - 1u && e < EGR_EXT_BLOCK) {
-                    v.ext_keys[(size_t)ext * EGR_EXT_BLOCK + e] = t;
-                    v.ext_vals[(size_t)ext * EGR_EXT_BLOCK + e] = make_float2(alpha, u2f(prim));
-                    cnt++;
-                } else {
-                    overflow = true;
-                }
-            }
-        };
-        // Tile coherence decides HOW the tree is walked. Coherent tiles (all primary tiles, mirror-like bounces) walk
-        // it as ONE packet: the node index is wave-uniform, nodes / leaf transforms come through the
-        // scalar cache (one request per wave instead of 64 divergent gathers), every lane tests its own ray and a node
-        // is entered when ANY lane overlaps it. Incoherent tiles walk per lane.
-        bool packet;
-        {
-            f3 dsum = mk3(ray_ok ? rd.x : 0.0f, ray_ok ? rd.y : 0.0f, ray_ok ? rd.z : 0.0f);
-            f3 osum = mk3(ray_ok ? ro.x : 0.0f, ray_ok ? ro.y : 0.0f, ray_ok ? ro.z : 0.0f);
-            float nok = ray_ok ? 1.0f : 0.0f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                dsum.x += __shfl_xor(dsum.x, off), dsum.y += __shfl_xor(dsum.y, off), dsum.z += __shfl_xor(dsum.z, off);
-                osum.x += __shfl_xor(osum.x, off), osum.y += __shfl_xor(osum.y, off), osum.z += __shfl_xor(osum.z, off);
-                nok += __shfl_xor(nok, off);
-            }
-            f3 dmean = normalize(dsum), omean = osum * (1.0f / fmaxf(nok, 1.0f));
-            float cmin = ray_ok ? dot(rd, dmean) : 1.0f, omax = ray_ok ? length(ro - omean) : 0.0f;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) cmin = fminf(cmin, __shfl_xor(cmin, off)), omax = fmaxf(omax, __shfl_xor(omax, off));
-            packet = v.packet_mode == 2 ? (cmin >= v.packet_cos_min && omax <= v.packet_origin_max) : (v.packet_mode == 1 && step == 0);
-            packet = __builtin_amdgcn_readfirstlane(packet ? 1 : 0) != 0;
-        }
-        // The tree bounds each gaussian's ELLIPSOID (image of the unit sphere), not its cube: an accepted hit's response
-        // point lies inside the ellipsoid (|u|^2 <= 1, shaders.cu:48), so walking a segment finds every accepted hit whose
-        // response point lies on that segment, with far fewer false-positive record fetches than cube boxes (the walk is
-        // bound by random cache-line fetches). The reference also accepts hits whose response point lies OUTSIDE
-        // [tmin,tmax] as long as the cube overlaps the segment (quirk Q1): those are exactly the hits found by walking
-        // [0,tmin) and (tmax,inf) and keeping the ones whose cube still overlaps [tmin,tmax] (the cube test below always
-        // uses the launch's near/far planes). Three disjoint ownership ranges -> every accepted candidate counted once.
-        const bool group_walk = !packet && v.group_walk != 0;
-        if (group_walk) { // publish the rays; per-ray results accumulate in LDS over the three segments
-            rayt[0][lane] = ro.x, rayt[1][lane] = ro.y, rayt[2][lane] = ro.z, rayt[3][lane] = rd.x, rayt[4][lane] = rd.y, rayt[5][lane] = rd.z;
-            gcnt[lane] = 0u, gtrav[lane] = 0u, gT[lane] = 1.0f, gext[lane] = EGR_EXT_NONE;
-        }
-        // Segment 2 (t > far) can only hold candidates if some box lies farther than the far plane: with every box inside the
-        // build frame (no sentinels) that needs a frame corner farther than `far` from the ray origin.
-        bool beyond_far_empty = false;
-        if (!sentinels) {
-            const float fx0 = v.frame.ox - 2.0f / v.frame.sx, fx1 = v.frame.ox + 65534.0f / v.frame.sx;
-            const float fy0 = v.frame.oy - 2.0f / v.frame.sy, fy1 = v.frame.oy + 65534.0f / v.frame.sy;
-            const float fz0 = v.frame.oz - 2.0f / v.frame.sz, fz1 = v.frame.oz + 65534.0f / v.frame.sz;
-            const float dx = fmaxf(fabsf(ro.x - fx0), fabsf(ro.x - fx1)), dy = fmaxf(fabsf(ro.y - fy0), fabsf(ro.y - fy1)),
-                        dz = fmaxf(fabsf(ro.z - fz0), fabsf(ro.z - fz1));
-            const bool reaches = !(dx * dx + dy * dy + dz * dz < far_plane * far_plane * 0.999f); // NaN-safe: unknown counts as "reaches"
-            beyond_far_empty = __ballot(ray_ok && reaches) == 0ull;
-        }
-        seg_lo = near_plane, seg_hi = far_plane;
-        for (seg = 0; seg < 3; seg++) {
-            if (seg == 1) {
-                if (!(near_plane > 0.0f)) continue; // bounce steps start at 0: nothing before the segment
-                seg_lo = 0.0f, seg_hi = near_plane;
-            } else if (seg == 2) {
-                if (beyond_far_empty) continue; // no box reaches past the far plane for any ray of this tile
-                seg_lo = far_plane, seg_hi = 3.0e38f;
-            }
-        if (packet) {
-            // ---- packet walk: wave-uniform DFS over the 8-wide tree; stack in LDS (uniform address), node slots, leaf
-            // transforms and live records through the scalar cache; each lane tests its own ray, a child is entered /
-            // evaluated when ANY lane overlaps its box.
-            uint32_t *ustk = &lstk[0][0];
-            uint32_t usp = 0;
-            if (__ballot(ray_ok) != 0ull) {
-                if (lane == 0) ustk[0] = 0u;
-                usp = 1;
-            }
-            while (usp > 0) {
-                usp--;
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ustk[usp]);
-#ifdef EGR_TRAVERSAL_STATS
-                st_inner += (lane == 0);
-#endif
-#pragma unroll
-                for (int k = 0; k < EGR_WIDTH; k++) {
-                    const uint4 sl = load_u4_uniform(wnodes, w * EGR_WIDTH + (uint32_t)k);
-                    if (sl.w == EGR_EMPTY_SLOT) break; // uniform: slots are packed from 0
-                    const bool hit = ray_ok && slab(sl, invq, ncq);
-                    if (__ballot(hit) == 0ull) continue;
-#ifdef EGR_TRAVERSAL_STATS
-                    st_visits += hit ? 1u : 0u;
-#endif
-                    if (sl.w & EGR_LEAF_FLAG) {
-                        const uint32_t p = sl.w & ~EGR_LEAF_FLAG;
-#ifdef EGR_TRAVERSAL_STATS
-                        st_leafhits += hit ? 1u : 0u;
-                        st_outer += (lane == 0);
-#endif
-                        const float4 w0 = load_f4_uniform(v.inst_w, 4 * p), w1 = load_f4_uniform(v.inst_w, 4 * p + 1), w2 = load_f4_uniform(v.inst_w, 4 * p + 2);
-                        const float4 a2 = load_f4_uniform(v.inst_w, 4 * p + 3);
-                        if (hit) evaluate(p, w0, w1, w2, a2);
-                    } else {
-                        if (lane == 0) ustk[usp] = sl.w;
-                        usp++;
-                    }
-                }
-            }
-        } else if (group_walk) {
-            // ---- group walk: EIGHT LANES PER RAY. Lane m of a group tests child slot m of the ray's current node, so one
-            // 16-B load per lane fetches the whole 128-B node (one line per group and instruction instead of eight divergent
-            // loads per lane), the eight slab tests run in parallel, and a group works through its eight rays one after
-            // the other - its load is the SUM of eight rays (per-lane walks wait for the slowest of 64). Hit children are
-            // compacted with a ballot: inner nodes to the ray's LDS stack, leaves to the ray's queue (coalesced). Phase B
-            // evaluates a ray's queue eight entries at a time with the same groups. Rays stay in LDS (rayt).
-            const uint32_t g8 = (uint32_t)lane & ~7u, m = (uint32_t)lane & 7u, below = (1u << m) - 1u;
-            const bool hi_half = lane >= 32;
-            const uint32_t gshift = g8 & 31u;
-            const size_t scratch0 = (size_t)blockIdx.x * EGR_WAVE;
-            uint32_t *__restrict__ gstk = v.stack_spill + (size_t)blockIdx.x * EGR_GSTK * EGR_WAVE;
-            bool g_over = false;
-            gsp[lane] = ((act_mask >> lane) & 1ull) ? 1u : 0u; // finite ray of an active lane: one pending entry, the root
-            lstk[0][lane] = 0u;
-            // Rounds of (walk, evaluate): a ray whose leaf queue fills up is suspended - its stack column stays where it is -
-            // and resumes after the evaluation phase has drained the queue (the reference's candidate pool is global, a
-            // single grazing ray may overlap thousands of gaussians).
-            for (;;) {
-            gq[lane] = 0u;
-            uint32_t nlist;
-            {   // the unfinished rays, compacted: groups TAKE rays from this list as they become free (a static "group g walks
-                // rays 8g..8g+7" split leaves seven groups waiting for the one that drew the heavy rays)
-                const bool todo = gsp[lane] != 0u;
-                const unsigned long long tm = __ballot(todo);
-                if (todo) glist[__popcll(tm & ((1ull << lane) - 1ull))] = (uint32_t)lane;
-                nlist = (uint32_t)__popcll(tm);
-                if (lane == 0) gnext[0] = 0u, gnext[1] = 0u;
-            }
-            __syncthreads();
-#ifdef EGR_TRAVERSAL_STATS
-            const unsigned long long tga0 = __builtin_amdgcn_s_memtime();
-#endif
-            {   // ---------------- phase A
-                uint32_t j = g8, sp = 0, nq = 0;
-                bool done = false, open = false;
-                f3 ginv = mk3(0, 0, 0), gnc = mk3(0, 0, 0);
-                uint32_t *__restrict__ queue_j = v.cand_queue;
-                for (;;) {
-                    if ((sp == 0u || nq + (uint32_t)EGR_GPOP * EGR_WIDTH > v.cand_cap) && !done) { // group-uniform: close (finished or queue full), open the next
-                        if (open && m == 0u) gq[j] = nq, gsp[j] = sp;
-                        uint32_t idx = 0u;
-                        if (m == 0u) idx = atomicAdd(&gnext[0], 1u);
-                        idx = (uint32_t)__shfl((int)idx, (int)g8);
-                        if (idx >= nlist) {
-                            done = true, open = false;
-                        } else {
-                            j = glist[idx], open = true;
-                            const f3 o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
-                            ginv = mk3(1.0f / (d.x * v.frame.sx), 1.0f / (d.y * v.frame.sy), 1.0f / (d.z * v.frame.sz));
-                            gnc = mk3(-((o.x - v.frame.ox) * v.frame.sx + 2.0f) * ginv.x, -((o.y - v.frame.oy) * v.frame.sy + 2.0f) * ginv.y,
-                                      -((o.z - v.frame.oz) * v.frame.sz + 2.0f) * ginv.z);
-                            queue_j = v.cand_queue + (scratch0 + j) * v.cand_cap;
-                            nq = 0u, sp = gsp[j];
-                        }
-                    }
-                    if (__ballot(!done) == 0ull) break;
-                    if (!done) {
-                        // pop up to EGR_GPOP nodes: that many independent line fetches in flight per group (the order in which
-                        // subtrees are visited is irrelevant: every overlapping leaf is collected). A tile's critical path is its
-                        // groups' eight rays walked one after the other, so the fetches per iteration set the latency of a tile.
-                        auto pop = [&]() {
-                            sp--;
-                            uint32_t w = lstk[min(sp, (uint32_t)EGR_LSTK - 1u)][j];
-                            if (sp >= EGR_LSTK) w = *reinterpret_cast<const volatile uint32_t *>(gstk + (size_t)(sp - EGR_LSTK) * EGR_WAVE + j);
-                            return w;
-                        };
-                        uint4 sl_[EGR_GPOP];
-                        uint32_t npop = 0;
-#pragma unroll
-                        for (int u = 0; u < EGR_GPOP; u++) {
-                            sl_[u] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, EGR_EMPTY_SLOT);
-                            if (sp > 0u) {
-                                const uint32_t w = pop();
-                                sl_[u] = wnodes[(size_t)w * EGR_WIDTH + m];
-                                npop++;
-                            }
-                        }
-#ifdef EGR_TRAVERSAL_STATS
-                        st_visits += (m == 0u) ? npop : 0u;
-                        if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
-#endif
-                        auto process = [&](const uint4 &sl) {
-                            const bool hit = sl.w != EGR_EMPTY_SLOT && slab(sl, ginv, gnc); // (the slab test orders the planes per axis: an inverted box is not empty)
-                            const bool leaf = (int)sl.w < 0;
-                            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit), lm = __builtin_amdgcn_ballot_w64(leaf);
-                            const unsigned long long im = hm & ~lm, fm = hm & lm; // scalar: inner / leaf children hit, whole wave
-                            // this lane's group: 8 bits of its 32-bit half
-                            const uint32_t gi = __builtin_amdgcn_ubfe(hi_half ? (uint32_t)(im >> 32) : (uint32_t)im, gshift, 8u);
-                            const uint32_t gl = __builtin_amdgcn_ubfe(hi_half ? (uint32_t)(fm >> 32) : (uint32_t)fm, gshift, 8u);
-                            if (hit && !leaf) {
-                                const uint32_t at = sp + (uint32_t)__popc(gi & below);
-                                if (at < EGR_LSTK) lstk[at][j] = sl.w;
-                                else if (at < EGR_LSTK + EGR_GSTK) gstk[(size_t)(at - EGR_LSTK) * EGR_WAVE + j] = sl.w;
-                                else g_over = true;
-                            }
-                            sp = min(sp + (uint32_t)__popc(gi), (uint32_t)(EGR_LSTK + EGR_GSTK));
-                            if (hit && leaf) {
-                                const uint32_t at = nq + (uint32_t)__popc(gl & below);
-                                if (at < v.cand_cap) queue_j[at] = sl.w & ~EGR_LEAF_FLAG;
-                                else g_over = true;
-                            }
-                            nq = min(nq + (uint32_t)__popc(gl), v.cand_cap);
-                        };
-#pragma unroll
-                        for (int u = 0; u < EGR_GPOP; u++) process(sl_[u]); // a slot that was not popped is an empty slot
-                    }
-                }
-            }
-            __syncthreads();
-#ifdef EGR_TRAVERSAL_STATS
-            const unsigned long long tga1 = __builtin_amdgcn_s_memtime();
-#endif
-            {   // the rays with queued leaves, compacted (same hand-out as phase A)
-                // longest queue first: a long ray taken last would leave the other groups idle while it is evaluated
-                const uint32_t myq = gq[lane];
-                uint32_t rank = 0u;
-#pragma unroll 1
-                for (int l = 0; l < EGR_WAVE; l += 4) {
-                    const uint4 q4 = *reinterpret_cast<const uint4 *>(&gq[l]);
-                    rank += (q4.x > myq || (q4.x == myq && l < lane)) ? 1u : 0u;
-                    rank += (q4.y > myq || (q4.y == myq && l + 1 < lane)) ? 1u : 0u;
-                    rank += (q4.z > myq || (q4.z == myq && l + 2 < lane)) ? 1u : 0u;
-                    rank += (q4.w > myq || (q4.w == myq && l + 3 < lane)) ? 1u : 0u;
-                }
-                if (myq != 0u) glist[rank] = (uint32_t)lane;
-                nlist = (uint32_t)__popcll(__ballot(myq != 0u));
-            }
-            __syncthreads();
-            {   // ---------------- phase B
-                uint32_t j = g8, nqj = 0, k0 = 0, cntg = 0, travg = 0, extj = EGR_EXT_NONE;
-                bool done = false, open = false;
-                float Tpart = 1.0f;
-                f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-                const uint32_t *__restrict__ queue_j = v.cand_queue;
-                float *__restrict__ keys_j = v.cand_keys;
-                float2 *__restrict__ vals_j = v.cand_vals;
-                for (;;) {
-                    if (k0 >= nqj && !done) { // group-uniform: close the finished ray, open the next one with queued leaves
-                        if (open) {
-                            float Tp = Tpart; // product of the eight lanes' partial products (deterministic order)
-                            Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 1)), Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 2)), Tp = (float)((double)Tp * (double)__shfl_xor(Tp, 4));
-                            if (m == 0u) gcnt[j] = cntg, gtrav[j] += travg, gT[j] = (float)((double)gT[j] * (double)Tp);
-                        }
-                        uint32_t idx = 0u;
-                        if (m == 0u) idx = atomicAdd(&gnext[1], 1u);
-                        idx = (uint32_t)__shfl((int)idx, (int)g8);
-                        if (idx >= nlist) {
-                            done = true, open = false;
-                        } else {
-                            j = glist[idx], open = true;
-                            o = mk3(rayt[0][j], rayt[1][j], rayt[2][j]), d = mk3(rayt[3][j], rayt[4][j], rayt[5][j]);
-                            queue_j = v.cand_queue + (scratch0 + j) * v.cand_cap;
-                            keys_j = v.cand_keys + (scratch0 + j) * v.cand_cap, vals_j = v.cand_vals + (scratch0 + j) * v.cand_cap;
-                            nqj = gq[j], k0 = 0u, cntg = gcnt[j], travg = 0u, Tpart = 1.0f, extj = gext[j];
-                        }
-                    }
-                    if (__ballot(!done) == 0ull) break;
-                    if (!done) {
-                        const uint32_t k = k0 + m;
-                        const bool have = k < nqj;
-                        int res = 0;
-                        float t = 0.0f, alpha = 0.0f;
-                        uint32_t pidx = 0u;
-                        if (have) {
-                            pidx = queue_j[k];
-                            const float4 w0 = v.inst_w[4 * pidx], w1 = v.inst_w[4 * pidx + 1], w2 = v.inst_w[4 * pidx + 2];
-                            res = test_candidate(o, d, pidx, w0, w1, w2, v.inst_w + 4 * (size_t)pidx + 3, t, alpha);
-                        }
-#ifdef EGR_TRAVERSAL_STATS
-                        st_leafhits += have ? 1u : 0u;
-                        st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
-#endif
-                        const uint32_t gc = (uint32_t)(__ballot(res >= 1) >> g8) & 0xFFu, ga = (uint32_t)(__ballot(res == 2) >> g8) & 0xFFu;
-                        if (cntg + (uint32_t)__popc(ga) > v.cand_cap && extj == EGR_EXT_NONE) { // group-uniform: the list outgrows its run
-                            uint32_t e = EGR_EXT_NONE;
-                            if (m == 0u) e = ext_alloc(), gext[j] = e;
-                            extj = (uint32_t)__shfl((int)e, (int)g8); // from the group's lane 0 (an LDS round trip within one statement
-                                                                      // sequence is a data race the compiler may "optimise")
-                        }
-                        if (res == 2) {
-                            const uint32_t at = cntg + (uint32_t)__popc(ga & below);
-                            if (at < v.cand_cap) {
-                                keys_j[at] = t, vals_j[at] = make_float2(alpha, u2f(pidx));
-                            } else if (extj < EGR_EXT_NONE - 1u && at - v.cand_cap < EGR_EXT_BLOCK) {
-                                v.ext_keys[(size_t)extj * EGR_EXT_BLOCK + (at - v.cand_cap)] = t;
-                                v.ext_vals[(size_t)extj * EGR_EXT_BLOCK + (at - v.cand_cap)] = make_float2(alpha, u2f(pidx));
-                            } else {
-                                g_over = true;
-                            }
-                            Tpart = (float)((double)Tpart * (1.0 - (double)alpha)); // :70 (Q1: over ALL accepted candidates)
-                        }
-                        cntg = min(cntg + (uint32_t)__popc(ga), v.cand_cap + (extj < EGR_EXT_NONE - 1u ? EGR_EXT_BLOCK : 0u));
-                        travg += (uint32_t)__popc(gc);
-                        k0 += 8u;
-                    }
-                }
-            }
-            __syncthreads();
-#ifdef EGR_TRAVERSAL_STATS
-            if (lane == 0) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0)), tga1 - tga0);
-                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0) + 2), __builtin_amdgcn_s_memtime() - tga1);
-            }
-#endif
-            if (__ballot(gsp[lane] != 0u) == 0ull) break;
-            }
-            if (__ballot(g_over) != 0ull) overflow = true;
-        } else {
-            // ---- per-lane walk: DFS with a per-lane stack (LDS [depth][lane], conflict-free; deeper entries spill to a
-            // per-wave global column). Phase A queues the leaves whose box the lane's segment overlaps, phase B evaluates
-            // them (decoupled so that the wave does not rendezvous at every leaf).
-            uint32_t *__restrict__ queue = v.cand_queue + ((size_t)blockIdx.x * EGR_WAVE + lane) * v.cand_cap;
-            uint32_t *__restrict__ gstk = v.stack_spill + (size_t)blockIdx.x * EGR_GSTK * EGR_WAVE;
-            uint32_t sp = 0;
-            auto push = [&](uint32_t x) {
-                if (sp < EGR_LSTK) lstk[sp][lane] = x, sp++;
-                else if (sp < EGR_LSTK + EGR_GSTK) gstk[(size_t)(sp - EGR_LSTK) * EGR_WAVE + lane] = x, sp++;
-                else overflow = true; // > 256 pending subtrees: cannot happen for trees the builder produces
-            };
-            if (ray_ok) push(0u);
-            // leaf ids are staged four at a time in registers: one 16-B store / load per four queue entries (every store is
-            // its own L2 write request on the write-through L1, and L2 requests per ray are what bounds this kernel)
-            uint4 pend = make_uint4(0u, 0u, 0u, 0u);
-            uint32_t np = 0;
-#ifdef EGR_TRAVERSAL_STATS
-            unsigned long long tA = 0, tB = 0;
-#endif
-            for (;;) {
-#ifdef EGR_TRAVERSAL_STATS
-                const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
-#endif
-                while (sp > 0 && nq + 4u + EGR_WIDTH <= v.cand_cap) { // phase A
-                    sp--;
-                    uint32_t w = lstk[min(sp, (uint32_t)EGR_LSTK - 1u)][lane]; // always an LDS read (a select of the two addresses compiles to a FLAT load)
-                    if (sp >= EGR_LSTK) w = *reinterpret_cast<const volatile uint32_t *>(gstk + (size_t)(sp - EGR_LSTK) * EGR_WAVE + lane); // rare spill; volatile keeps it a separate global load
-                    const uint4 *__restrict__ nd = wnodes + (size_t)w * EGR_WIDTH;
-                    uint4 sl[EGR_WIDTH];
-#pragma unroll
-                    for (int k = 0; k < EGR_WIDTH; k++) sl[k] = nd[k]; // eight 16-B loads of ONE 128-B line
-#ifdef EGR_TRAVERSAL_STATS
-                    st_visits++;
-                    if (lane == __ffsll((long long)__ballot(1)) - 1) st_inner++;
-#endif
-#pragma unroll
-                    for (int k = EGR_WIDTH - 1; k >= 0; k--) { // reverse: slot 0 is popped first
-                        if (sl[k].w == EGR_EMPTY_SLOT) continue;
-                        if (!slab(sl[k], invq, ncq)) continue;
-                        if (sl[k].w & EGR_LEAF_FLAG) {
-                            const uint32_t id = sl[k].w & ~EGR_LEAF_FLAG;
-                            pend.x = np == 0u ? id : pend.x, pend.y = np == 1u ? id : pend.y, pend.z = np == 2u ? id : pend.z, pend.w = np == 3u ? id : pend.w;
-                            if (++np == 4u) *reinterpret_cast<uint4 *>(queue + nq) = pend, nq += 4u, np = 0u;
-                        } else
-                            push(sl[k].w);
-                    }
-                }
-                if (np) *reinterpret_cast<uint4 *>(queue + nq) = pend, nq += np, np = 0u; // partial last group
-#ifdef EGR_TRAVERSAL_STATS
-                st_leafhits += nq;
-                const unsigned long long ta1 = __builtin_amdgcn_s_memtime();
-                tA += ta1 - ta0;
-#endif
-                uint4 grp = make_uint4(0u, 0u, 0u, 0u);
-                for (uint32_t q = 0; q < nq; q++) { // phase B
-                    if ((q & 3u) == 0u) grp = *reinterpret_cast<const uint4 *>(queue + q);
-                    const uint32_t j = q & 3u, p = j == 0u ? grp.x : j == 1u ? grp.y : j == 2u ? grp.z : grp.w;
-#ifdef EGR_TRAVERSAL_STATS
-                    st_outer += (lane == __ffsll((long long)__ballot(1)) - 1);
-#endif
-                    // one 64-B record per candidate: rows of W, then (f0.z, rough, opacity, sigma) - fetched only on acceptance
-                    const float4 w0 = v.inst_w[4 * p], w1 = v.inst_w[4 * p + 1], w2 = v.inst_w[4 * p + 2];
-                    evaluate(p, w0, w1, w2, v.inst_w + 4 * (size_t)p + 3);
-                }
-                nq = 0;
-#ifdef EGR_TRAVERSAL_STATS
-                tB += __builtin_amdgcn_s_memtime() - ta1;
-#endif
-                if (__ballot(sp > 0) == 0ull) break;
-            }
-#ifdef EGR_TRAVERSAL_STATS
-            if (lane == 0) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0)), tA);
-                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8 + 4 * (step > 0) + 2), tB);
-            }
-#endif
-        }
-
-        }
-        if (group_walk) cnt = gcnt[lane], traversed = gtrav[lane], full_T = gT[lane], ext = gext[lane];
-#ifdef EGR_DEBUG_LIST
-        if (active && cnt > 0 && cnt <= v.cand_cap) {
-            double p = 1.0;
-            for (uint32_t k = 0; k < cnt; k++) p *= 1.0 - (double)vals[k].x;
-            if (fabs(p - (double)full_T) > 1e-4 * fmax(p, (double)full_T) + 1e-12) {
-                printf("[list mismatch] step %d task %u lane %d cnt %u prodlist %.9g full_T %.9g group %d\n", step, task, lane, cnt, p, (double)full_T, (int)group_walk);
-                for (uint32_t k = 0; k < cnt && k < 40; k++) printf("   k %u t %.9g alpha %.9g pos %u\n", k, (double)keys[k], (double)vals[k].x, f2u(vals[k].y));
-            }
-        }
-#endif
-#ifdef EGR_TRAVERSAL_STATS
-        const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
-        {
-            uint32_t a = wave_sum_u32(st_visits), b = wave_sum_u32(st_leafhits), c2 = wave_sum_u32(st_inner), d = wave_sum_u32(st_outer);
-            if (lane == 0) add64(v.control, CW_DBG + 8 * (step > 0), a), add64(v.control, CW_DBG + 8 * (step > 0) + 2, b), add64(v.control, CW_DBG + 8 * (step > 0) + 4, c2), add64(v.control, CW_DBG + 8 * (step > 0) + 6, d);
-        }
-#endif
-        // ---- R3: depth-ordered compositing (forward_pass.cu:48-137) --------------------------------------
-        f3 c_rgb = mk3(0, 0, 0), c_n = mk3(0, 0, 0), c_f0 = mk3(0, 0, 0);
-        float c_rough = 0.0f, c_depth = 0.0f, T = 1.0f;
-        uint32_t nhits = 0;
-        {
-            float t_prev = near_plane;    // strict '>' against tmin (forward_pass.cu:62)
-            uint32_t k_prev = 0xFFFFFFFFu; // ties: continue in list order after the previous pick
-            bool running = active && cnt > 0;
-            uint32_t last_block = 0xFFFFFFFFu, cur_block = 0xFFFFFFFFu;
-            bool recording = GRADS;
-            // Depth order in batches of 8 (= one arena block): ONE scan over the lane's key column keeps the 8 strict
-            // successors of (t_prev, k_prev) in (t, k) lexicographic order in registers (sorted insertion, static indices),
-            // then the batch is composited front to back. The old "one scan per composited hit" cost Kc+1 passes.
-            for (uint32_t it = 0;; it += EGR_HIT_BLOCK_ROWS) {
-                float kt[8];
-                uint32_t ki[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) kt[j] = 3.4028235e38f, ki[j] = 0xFFFFFFFFu;
-                if (running) {
-                    auto consider = [&](float tk, uint32_t k) {
-                        const bool after = (tk > t_prev) || (tk == t_prev && k > k_prev && k_prev != 0xFFFFFFFFu);
-                        if (after && tk < kt[7]) { // displaces the current 8th: bubble into place (stable: equal t keeps list order)
-                            float xt = tk;
-                            uint32_t xi = k;
-                            bool shifting = false; // once the new key has found its place everything behind it moves one slot to the right
-#pragma unroll                                     // (comparing the carried element with '<' again would put it BEHIND an equal key)
-                            for (int j = 0; j < 8; j++) {
-                                const bool sw = shifting || xt < kt[j];
-                                shifting = sw;
-                                const float ot = kt[j];
-                                const uint32_t oi = ki[j];
-                                kt[j] = sw ? xt : ot, ki[j] = sw ? xi : oi;
-                                xt = sw ? ot : xt, xi = sw ? oi : xi;
-                            }
-                        }
-                    };
-                    // two 16-B loads per 8 keys (cand_cap is a multiple of 8, so runs are 32-B aligned), in flight together
-                    const uint32_t nbase = min(cnt, v.cand_cap);
-                    uint32_t k = 0;
-                    for (; k + 8 <= nbase; k += 8) {
-                        const float4 ka = *reinterpret_cast<const float4 *>(keys + k), kb = *reinterpret_cast<const float4 *>(keys + k + 4);
-                        consider(ka.x, k), consider(ka.y, k + 1), consider(ka.z, k + 2), consider(ka.w, k + 3);
-                        consider(kb.x, k + 4), consider(kb.y, k + 5), consider(kb.z, k + 6), consider(kb.w, k + 7);
-                    }
-                    for (; k < nbase; k++) consider(keys[k], k);
-                    for (; k < cnt; k++) consider(v.ext_keys[(size_t)ext * EGR_EXT_BLOCK + (k - v.cand_cap)], k); // the extension block (rare)
-                    if (ki[0] == 0xFFFFFFFFu || !(kt[0] < far_plane)) running = false; // :81, :91-93
-                }
-                if (__ballot(running) == 0ull) break;
-                if (GRADS && recording) { // one arena block per batch per wave
-                    uint32_t blk = 0;
-                    if (lane == 0) blk = atomicAdd(v.control + CW_HIT_BUMP, 1u);
-                    blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk);
-                    if (blk >= v.hit_blocks_cap) {
-                        recording = false;
-                        if (lane == 0) atomicOr(v.control + CW_STATUS, EGR_STATUS_HIT_ARENA_OVERFLOW);
-                    } else {
-                        if (lane == 0) v.hit_arena[(size_t)blk * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE] = make_float4(u2f(last_block), 0, 0, 0);
-                        last_block = cur_block = blk;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (running && (ki[j] == 0xFFFFFFFFu || !(kt[j] < far_plane))) running = false; // list exhausted / beyond zfar
-                    if (running) {
-                        const float best = kt[j];
-                        t_prev = best;
-                        k_prev = ki[j];
-                        float2 av = ki[j] < v.cand_cap ? vals[ki[j]] : v.ext_vals[(size_t)ext * EGR_EXT_BLOCK + (ki[j] - v.cand_cap)];
-                        float alpha = av.x;
-                        uint32_t pos = f2u(av.y); // record index (sorted position)
-                        float4 a0 = app[2 * pos], a1 = app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
-                        float next_T = T * (1.0f - alpha);       // :108
-                        float weight = T - next_T;               // :109
-                        c_rgb = c_rgb + mk3(a0.x, a0.y, a0.z) * weight;
-                        c_n = c_n + mk3(a0.w, a1.x, a1.y) * weight;
-                        c_f0 = c_f0 + mk3(a1.z, a1.w, a2.x) * weight;
-                        c_rough += a2.y * weight;
-                        c_depth += best * weight;
-                        T = next_T;
-                        nhits++;
-                        if (GRADS && recording)
-                            v.hit_arena[((size_t)cur_block * (EGR_HIT_BLOCK_ROWS + 1) + 1 + j) * EGR_WAVE + lane] = make_float4(u2f(pos), best, alpha, T);
-                        if (T < transmittance_threshold || nhits >= EGR_MAX_COMPOSITED_PER_RAY) running = false; // :131-134, :55
-                    }
-                }
-            }
-            if (GRADS) {
-                // arena exhausted: forward results stay exact, backward skips this task (status flag is raised)
-                if (lane == 0) v.task_last_block[chain_head] = recording ? last_block : 0xFFFFFFFFu;
-                if (mine) S.st(SF(step, S_NHITS), u2f(recording ? nhits : 0u));
-            }
-        }
-        if (overflow && active) atomicOr(v.control + CW_STATUS, EGR_STATUS_CANDIDATE_OVERFLOW);
-
-#ifdef EGR_TRAVERSAL_STATS
-        {
-            const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-            if (lane == 0) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 4 * (step > 0)), tm1 - tm0);
-                atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 4 * (step > 0) + 2), tm2 - tm1);
-            }
-        }
-#endif
-        // ---- raw step results; R4/R5 (tail renormalisation, bounce sampling) run in k_step_epilogue (epilogue.hip),
-        // which is compiled without fma contraction (see the note there).
-        if (active) {
-            S.st3(SF(step, S_RGB), c_rgb), S.st(SF(step, S_DEPTH), c_depth), S.st3(SF(step, S_NORMAL), c_n);
-            S.st3(SF(step, S_F0), c_f0), S.st(SF(step, S_ROUGH), c_rough), S.st(SF(step, S_T), T), S.st(SF(step, S_TTOT), full_T);
-            if (step == 0) {
-                S.st3(F_RAY_O, ro), S.st3(F_RAY_D, rd);
-                S.st(F_SEED, u2f(seed));
-            }
-            v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)nhits;  // forward_pass.cu:140 (last step wins)
-            if (step == 0) v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)traversed;
-            else v.stats.num_traversed_per_pixel[tg.pixel_id] += (int32_t)traversed; // forward_pass.cu:46
-        }
-#ifdef EGR_TASK_TIMES // diagnostic build: the tile's first pixel carries the task's start / end time of one step (which must be the last)
-        if (step == EGR_TASK_TIMES && lane == 0 && tg.inside && mine) {
-            v.stats.num_traversed_per_pixel[tg.pixel_id] = (int32_t)(tt0 & 0x7FFFFFFFull); // start / end, 10 ns ticks
-            v.stats.num_accumulated_per_pixel[tg.pixel_id] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7FFFFFFFull);
-        }
-#endif
+#include "forward_task.inc"
         w_rays += active ? 1u : 0u;
         w_cand += active ? traversed : 0u;
         w_comp += active ? nhits : 0u;
@@ -921,6 +255,39 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 #endif
     w_rays = wave_sum_u32(w_rays), w_cand = wave_sum_u32(w_cand), w_comp = wave_sum_u32(w_comp);
     if (lane == 0) add64(v.control, CW_RAYS + 2 * step, w_rays), add64(v.control, CW_CAND + 2 * step, w_cand), add64(v.control, CW_COMP + 2 * step, w_comp);
+}
+
+// The fused per-tile chain: a wave takes a tile through ALL its steps (trace, step epilogue, trace, ...) before it takes the
+// next tile. A rank's forward time is then max over tiles of (sum of its steps) instead of the sum over steps of (max over
+// tiles). The launch path uses it when a rank holds few tiles per wave slot (multi-GPU partitions): every step kernel then
+// lasts as long as its heaviest tile, and a tile's cost at one step says nothing about its cost at the next.
+// Same per-step code as k_forward (forward_task.inc) and the same step epilogue as k_step_epilogue (egr_epilogue.hpp).
+template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_forward_chain(DeviceView v) {
+#include "forward_decl.inc"
+    __shared__ uint32_t wc[3 * EGR_NSTEPS]; // this wave's ray / candidate / composited counts per step
+    if (lane < 3 * EGR_NSTEPS) wc[lane] = 0u;
+    __syncthreads();
+    uint32_t cur_q = blockIdx.x & 7u;
+    constexpr bool split = false;
+
+    for (;;) {
+        const uint32_t tq = wave_next_task(v.queues, v.task_count, cur_q);
+        if (tq == 0xFFFFFFFFu) break;
+        for (int step = 0; step <= num_bounces; step++) {
+            do { // (a `continue` in the step body ends the step)
+                const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
+#include "forward_task.inc"
+                const uint32_t a = wave_sum_u32(active ? 1u : 0u), b = wave_sum_u32(active ? traversed : 0u), c2 = wave_sum_u32(active ? nhits : 0u);
+                if (lane == 0) wc[3 * step] += a, wc[3 * step + 1] += b, wc[3 * step + 2] += c2;
+            } while (false);
+            // R4 / R5 of this step for the tile's rays
+            const uint32_t etask = v.task_begin + tq;
+            const TaskGeom etg = task_geom(v, etask, lane);
+            if (etg.inside) step_epilogue_lane(v, step, GRADS, num_bounces, etg, StateRef{v.state, v.state_stride, etask * EGR_WAVE + (uint32_t)lane});
+        }
+    }
+    __syncthreads();
+    if (lane < EGR_NSTEPS) add64(v.control, CW_RAYS + 2 * lane, wc[3 * lane]), add64(v.control, CW_CAND + 2 * lane, wc[3 * lane + 1]), add64(v.control, CW_COMP + 2 * lane, wc[3 * lane + 2]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1634,7 +1001,16 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             const bool split = c->group_walk && (c->split_mode == 1 || (c->split_mode < 0 && (double)w.task_count < c->split_below * (double)c->num_slots));
             w.split_mask = split ? 0x6u : 0u; // steps 1, 2
             const dim3 qgrid(std::max(1u, std::min(c->num_slots, w.task_count * 4u)));
-            for (int step = 0; step < EGR_NSTEPS; step++) {
+            // Few tiles per wave slot: every step kernel lasts as long as its heaviest tile, and a tile's cost at one step says
+            // nothing about its cost at the next (measured correlation -0.2 .. -0.07): run the fused per-tile chain.
+            const bool chain = !split && (c->chain_mode == 1 || (c->chain_mode < 0 && (double)w.task_count < c->chain_below * (double)c->num_slots));
+            if (chain) {
+                egr_stamp_begin(c, "forward_chain", ls);
+                if (grads) hipLaunchKernelGGL(k_forward_chain<true>, sgrid, block, 0, ls, w);
+                else hipLaunchKernelGGL(k_forward_chain<false>, sgrid, block, 0, ls, w);
+                egr_stamp_end(c, ls);
+            }
+            for (int step = 0; step < EGR_NSTEPS && !chain; step++) {
                 egr_stamp_begin(c, fn[step], ls);
                 const dim3 fgrid = ((w.split_mask >> step) & 1u) ? qgrid : sgrid;
                 if (grads) hipLaunchKernelGGL(k_forward<true>, fgrid, block, 0, ls, w, step);

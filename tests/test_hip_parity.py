@@ -502,6 +502,40 @@ def test_quarter_tile_split_does_not_change_results(ren, orc, syn, monkeypatch):
         assert np.abs(res["0"][1][k] - res["1"][1][k]).max() / (np.abs(res["0"][1][k]).max() + 1e-30) < 1e-4, k
 
 
+def test_fused_tile_chain_does_not_change_results(ren, orc, syn, monkeypatch):
+    """The fused per-tile forward chain (one wave takes a tile through all its steps, with the step epilogue inlined from the
+    contraction-free header; what a rank with few tiles per wave slot runs, EGR_CHAIN) gives bit-identical images, states and
+    counters as the step-by-step kernels, and the same gradients."""
+    W, H = 200, 136
+    g = syn.make_scene(20000, "trained", seed=4)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EGR_CHAIN", mode)
+        monkeypatch.setenv("EGR_SPLIT", "0")
+        rt, _ = make_pair(ren, orc, g, cam, W, H, fwd=40_000_000, bwd=40_000_000)
+        m = rt.cuda_module
+        m.get_config().num_bounces.fill_(2)
+        with torch.no_grad():
+            rt(cam_obj(ren, cam))
+        img = hip_outputs(rt)
+        seeds = m.get_metadata().random_seeds.cpu().numpy().copy()
+        m.get_metadata().total_num_calls.zero_()
+        run_grad(ren, rt, cam_obj(ren, cam, tg))
+        c = m.get_counters()
+        assert c[11] == 0, "status"
+        res[mode] = (img, hip_grads(rt), list(c[:9]), seeds)
+        del rt
+    for k in OUT_KEYS:
+        assert np.array_equal(res["0"][0][k], res["1"][0][k]), k
+    assert np.array_equal(res["0"][3], res["1"][3])
+    assert res["0"][2] == res["1"][2]
+    assert res["0"][2][1] > 0 and res["0"][2][7] > 0  # bounce rays were traced and composited
+    for k in GRAD_KEYS:
+        assert np.abs(res["0"][1][k] - res["1"][1][k]).max() / (np.abs(res["0"][1][k]).max() + 1e-30) < 1e-4, k
+
+
 # ------------------------------------------------------------------------------------------------ full size
 def test_full_size_properties_1080p_1M(ren, orc, syn):
     """BASELINE config C (1080p, 1M Gaussians): size-independent properties instead of a full oracle run."""
