@@ -209,6 +209,8 @@ def main():
                 cands[f"backward_step{s}"] = algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank)
         if "forward_chain" in kern:  # the fused per-tile chain ran (few tiles per wave slot): one kernel does the three forward steps
             cands["forward_chain"] = sum(cands.pop(f"forward_step{s}") for s in range(3))
+        if "backward_chain" in kern:
+            cands["backward_chain"] = sum(cands.pop(f"backward_step{s}") for s in range(3))
         dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
         achieved = cands[dom] / (kern[dom] * 1e-3) / 1e9
         # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes of this command (profiles/<round>/

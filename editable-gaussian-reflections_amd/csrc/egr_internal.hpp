@@ -170,7 +170,7 @@ struct egr_context {
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
     int bucketed_backward = 2; // bounce-step backward: 0 atomics on the gradient rows, 1 per-block buckets + counting-sort reduce, 2 per-wave record logs + apply
     int group_walk = 1;
-    int chain_mode = -1;      // fused per-tile forward chain: -1 auto (few tiles per wave slot), 0 never, 1 always (EGR_CHAIN)
+    int chain_mode = 1;       // fused per-tile chains (k_forward_chain, k_backward_chain): 1 always (default), 0 never (step-by-step kernels), -1 only with few tiles per wave slot (EGR_CHAIN)
     double chain_below = 4.0; // auto: chain when a strand has fewer tiles than this many per wave slot (EGR_CHAIN_BELOW)
     int split_mode = 0;       // quarter-tile bounce steps: 0 never (default: measured neutral), 1 always, -1 auto (few tiles per wave slot) (EGR_SPLIT)
     double split_below = 2.0; // auto: split when a strand has fewer tiles than this many per wave slot (EGR_SPLIT_BELOW)

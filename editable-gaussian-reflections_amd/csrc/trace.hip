@@ -409,237 +409,51 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8 * (3 + step), v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
-        const uint32_t task = v.task_begin + tq;
-        // the tile's arena chain, or its four quarter chains (forward ran this step split): every lane follows its own
-        const bool split = !PRIMARY && ((v.split_mask >> step) & 1u) != 0u;
-        uint32_t blk = v.task_last_block[((size_t)step * v.num_tasks + task) * 4u + (split ? (uint32_t)lane >> 4 : 0u)];
-        if (__ballot(blk != 0xFFFFFFFFu) == 0ull) continue;
-        const TaskGeom tg = task_geom(v, task, lane);
-        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
-        uint32_t steps_done = tg.inside ? f2u(S.ld(F_STEPS)) : 0u;
-        uint32_t nhits = (tg.inside && (uint32_t)step < steps_done && blk != 0xFFFFFFFFu) ? f2u(S.ld(SF(step, S_NHITS))) : 0u; // shaders.cu:157-158
-        const uint32_t max_hits = wave_max_u32(nhits);
-        if (max_hits == 0) continue;
-        uint32_t chain_hits = max_hits; // hits of the longest ray recorded in this lane's chain
-        if (split) {
-            chain_hits = nhits;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) chain_hits = max(chain_hits, (uint32_t)__shfl_xor((int)chain_hits, off));
-        }
-        const uint32_t chain_blocks = (chain_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
-
-        // ---- B1: output gradients (backward_pass.cu:80-108); constant along the ray ----------------------
-        f3 dL_rgb = mk3(0, 0, 0), dL_n = mk3(0, 0, 0), dL_f0 = mk3(0, 0, 0);
-        float dL_depth = 0.0f, dL_rough = 0.0f;
-        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-        f3 rem_rgb = mk3(0, 0, 0), rem_n = mk3(0, 0, 0), rem_f0 = mk3(0, 0, 0);
-        float rem_depth = 0.0f, rem_rough = 0.0f, T_minus_Ttot = 0.0f;
-        if (nhits > 0) {
-            const uint32_t pid = tg.pixel_id;
-            const float third = 1.0f / 3.0f;
-            if (PRIMARY) {
-                f3 o_rgb = S.ld3(SF(0, S_RGB)), o_n = S.ld3(SF(0, S_NORMAL)), o_f0 = S.ld3(SF(0, S_F0));
-                float o_depth = S.ld(SF(0, S_DEPTH)), o_rough = S.ld(SF(0, S_ROUGH));
-                const float *td = v.fb.target_diffuse + 3 * (size_t)pid, *tn = v.fb.target_normal + 3 * (size_t)pid,
-                            *tf = v.fb.target_f0 + 3 * (size_t)pid;
-                dL_rgb = mk3(third * sign1(o_rgb.x - td[0]), third * sign1(o_rgb.y - td[1]), third * sign1(o_rgb.z - td[2])) * *v.cfg.loss_weight_diffuse;
-                dL_depth = sign1(o_depth - v.fb.target_depth[pid]) * *v.cfg.loss_weight_depth;
-                dL_n = mk3(third * sign1(o_n.x - tn[0]), third * sign1(o_n.y - tn[1]), third * sign1(o_n.z - tn[2])) * *v.cfg.loss_weight_normal;
-                dL_f0 = mk3(third * sign1(o_f0.x - tf[0]), third * sign1(o_f0.y - tf[1]), third * sign1(o_f0.z - tf[2])) * *v.cfg.loss_weight_f0;
-                dL_rough = sign1(o_rough - v.fb.target_roughness[pid]) * *v.cfg.loss_weight_roughness;
-                // primary ray is regenerated from the seed instead of being stored
-                uint32_t seed = tea4(pid, (uint32_t)*v.meta.total_num_calls);
-                ro = mk3(v.cam.origin[0], v.cam.origin[1], v.cam.origin[2]);
-                rd = primary_direction(v, tg.px, tg.py, *v.cfg.jitter_primary_rays != 0, seed);
-            } else {
-                f3 spec = mk3(0, 0, 0);
-                for (int j = 1; j < num_bounces + 1; j++)
-                    if ((uint32_t)j < steps_done) spec = spec + S.ld3(SF(j, S_RGB)); // unexecuted steps hold 0 upstream
-                const float *ts = v.fb.target_specular + 3 * (size_t)pid;
-                float down = powf(1.0f - S.ld(SF(step - 1, S_ROUGH)), EGR_ROUGHNESS_DOWNWEIGHT_GRAD_POWER); // :11-13
-                dL_rgb = (mk3(third * sign1(spec.x - ts[0]), third * sign1(spec.y - ts[1]), third * sign1(spec.z - ts[2])) *
-                          *v.cfg.loss_weight_specular) * down;
-                dL_rgb = dL_rgb * S.ld3(SF(step - 1, S_THR)); // :107, throughput of the previous step
-                ro = S.ld3(SF(step - 1, S_NEXT_O));
-                rd = S.ld3(SF(step - 1, S_NEXT_D));
-            }
-            rem_rgb = S.ld3(SF(step, S_REM_RGB)), rem_n = S.ld3(SF(step, S_REM_NORMAL)), rem_f0 = S.ld3(SF(step, S_REM_F0));
-            rem_depth = S.ld(SF(step, S_REM_DEPTH)), rem_rough = S.ld(SF(step, S_REM_ROUGH));
-            T_minus_Ttot = S.ld(SF(step, S_T)) - S.ld(SF(step, S_TTOT));
-        }
-
-        // ---- B2: per-hit chain -------------------------------------------------------------------------
-        f3 prev_rgb = mk3(0, 0, 0), w_rgb = mk3(0, 0, 0), prev_n = mk3(0, 0, 0), w_n = mk3(0, 0, 0), prev_f0 = mk3(0, 0, 0), w_f0 = mk3(0, 0, 0);
-        float prev_rough = 0, w_rough = 0, prev_depth = 0, w_depth = 0;
-        const uint32_t nblocks = (max_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
-        uint32_t new_slots = 0;
-        for (uint32_t b = nblocks; b-- > 0;) {
-            const bool in_chain = b < chain_blocks; // this lane's chain has a block for batch b
-            const float4 *rows = v.hit_arena + (size_t)(in_chain ? blk : 0u) * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE;
-            for (int row = EGR_HIT_BLOCK_ROWS - 1; row >= 0; row--) {
-                const uint32_t it = b * EGR_HIT_BLOCK_ROWS + (uint32_t)row;
-                if (it >= max_hits) continue;
-                // a hit that finds no table slot leaves the divergent block with its gradients in `dg`: the bucket append that
-                // follows is a wave-level operation
-                bool direct = false;
-                uint32_t dpos = 0;
-                float dg[GC_NORMAL]; // the 15 components a bounce step produces
-                if (it < nhits) {
-                    const float4 rec = rows[(size_t)(1 + row) * EGR_WAVE + lane];
-                    const uint32_t pos = f2u(rec.x);          // record index (sorted position)
-                    const float distance = rec.y, alpha = rec.z, transmittance = rec.w;
-                    const float4 a0 = v.app[2 * pos], a1 = v.app[2 * pos + 1], a2 = v.inst_w[4 * pos + 3];
-                    const f3 g_rgb = mk3(a0.x, a0.y, a0.z);
-                    const float opacity = a2.z, scaling_factor = a2.w;
-                    // recompute the local hit exactly as the forward did
-                    f3 lo, ld, dhat, u;
-                    float t_unused;
-                    object_ray(v.inst_w, pos, ro, rd, lo, ld);
-                    closest_point(lo, ld, dhat, t_unused, u);
-                    const f3 local_hit = u * scaling_factor;
-                    const float sq_norm = dot(local_hit, local_hit);
-                    const float gaussval = eval_gaussian_sq(sq_norm, exp_power);
-
-                    const float weight = (float)((double)transmittance / (1.0 - (double)alpha) * (double)alpha); // :111
-                    // activation backward is evaluated on the ACTIVATED value (activations.cu:29,41-43) -> pass-through
-                    f3 d_rgb = (dL_rgb * weight);
-                    f3 d_n = dL_n * weight, d_f0 = dL_f0 * weight;
-                    float d_rough = dL_rough * weight;
-
-                    w_rgb = w_rgb + (g_rgb - prev_rgb) * transmittance; // :118-132
-                    prev_rgb = g_rgb;
-                    if (PRIMARY) {
-                        f3 g_n = mk3(a0.w, a1.x, a1.y), g_f0 = mk3(a1.z, a1.w, a2.x);
-                        w_n = w_n + (g_n - prev_n) * transmittance;
-                        prev_n = g_n;
-                        w_f0 = w_f0 + (g_f0 - prev_f0) * transmittance;
-                        prev_f0 = g_f0;
-                        w_rough += (a2.y - prev_rough) * transmittance;
-                        prev_rough = a2.y;
-                        w_depth += (distance - prev_depth) * transmittance;
-                        prev_depth = distance;
-                    }
-                    float dL_dalpha = 0.0f; // :134-148
-                    const float tmp1 = 1.0f / (1.0f - alpha);
-                    dL_dalpha += dot(w_rgb * tmp1, dL_rgb);
-                    dL_dalpha += dot(w_n * tmp1, dL_n);
-                    dL_dalpha += dot(w_f0 * tmp1, dL_f0);
-                    dL_dalpha += (w_rough * tmp1) * dL_rough;
-                    dL_dalpha += (w_depth * tmp1) * dL_depth;
-                    const float tmp2 = -(T_minus_Ttot / (1.0f - alpha));
-                    dL_dalpha += tmp2 * dot(rem_rgb, dL_rgb);
-                    dL_dalpha += tmp2 * dot(rem_n, dL_n);
-                    dL_dalpha += tmp2 * dot(rem_f0, dL_f0);
-                    dL_dalpha += tmp2 * (rem_rough * dL_rough);
-                    dL_dalpha += tmp2 * (rem_depth * dL_depth);
-
-                    float d_opacity = EGR_MAX_ALPHA * dL_dalpha * gaussval; // :151-152
-                    d_opacity = d_opacity * opacity * (1.0f - opacity);
-                    const float dL_dgaussval = EGR_MAX_ALPHA * dL_dalpha * opacity; // :155-158
-                    const float dL_dsq_norm = gaussval * pow_exp_m1(sq_norm, exp_power);
-                    const f3 dL_dx_local = (-local_hit * dL_dsq_norm) * dL_dgaussval;
-                    const float4 W0 = v.inst_w[4 * pos], W1 = v.inst_w[4 * pos + 1], W2 = v.inst_w[4 * pos + 2];
-                    const f3 dL_dx_world = mk3(dot(mk3(W0.x, W1.x, W2.x), dL_dx_local), dot(mk3(W0.y, W1.y, W2.y), dL_dx_local),
-                                               dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
-                    const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
-                    const f3 d_mean = -dL_dx_world;
-                    const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3];
-                    const f3 scaling = mk3(M0.w, M1.w, M2.w); // exp(scale), stored by k_instances
-                    const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
-                                       scaling.z * scaling_factor + eps_scale_grad);
-                    const f3 rot_0 = mk3(M0.x, M0.y, M0.z) / den, rot_1 = mk3(M1.x, M1.y, M1.z) / den, rot_2 = mk3(M2.x, M2.y, M2.z) / den; // :178-180
-                    const f3 d_scale = (dl2w0 * rot_0 + dl2w1 * rot_1 + dl2w2 * rot_2) * scaling; // :181-182
-                    const f3 dr0 = dl2w0 * scaling, dr1 = dl2w1 * scaling, dr2 = dl2w2 * scaling; // :185-187
-                    const float qn = sqrtf(qu.x * qu.x + qu.y * qu.y + qu.z * qu.z + qu.w * qu.w);
-                    const float r = qu.x / qn, x = qu.y / qn, y = qu.z / qn, z = qu.w / qn; // activations.cu:66-69
-                    const float dL_dr = 2.f * x * (dr2.y - dr1.z) + 2.f * y * (dr0.z - dr2.x) + 2.f * z * (dr1.x - dr0.y); // :194-205
-                    const float dL_dx = -4.f * x * (dr1.y + dr2.z) + 2.f * y * (dr0.y + dr1.x) + 2.f * z * (dr0.z + dr2.x) + 2.f * r * (dr2.y - dr1.z);
-                    const float dL_dy = 2.f * x * (dr0.y + dr1.x) - 4.f * y * (dr0.x + dr2.z) + 2.f * z * (dr1.z + dr2.y) + 2.f * r * (dr0.z - dr2.x);
-                    const float dL_dz = 2.f * x * (dr0.z + dr2.x) + 2.f * y * (dr1.z + dr2.y) - 4.f * z * (dr0.x + dr1.y) + 2.f * r * (dr1.x - dr0.y);
-                    const float dd = dL_dr * qu.x + dL_dx * qu.y + dL_dy * qu.z + dL_dz * qu.w; // activations.cu:71-73
-                    const float inv3 = 1.0f / (qn * qn * qn), inv1 = 1.0f / qn;
-
-                    // :210-220 flush: into the LDS table when a slot is found within 8 probes, else straight to global
-                    const float d_rot0 = dd * -qu.x * inv3 + dL_dr * inv1, d_rot1 = dd * -qu.y * inv3 + dL_dx * inv1;
-                    const float d_rot2 = dd * -qu.z * inv3 + dL_dy * inv1, d_rot3 = dd * -qu.w * inv3 + dL_dz * inv1;
-                    float gx[EGR_GT_COMPS];
-                    gx[GC_OPA] = d_opacity, gx[GC_SCALE] = d_scale.x, gx[GC_SCALE + 1] = d_scale.y, gx[GC_SCALE + 2] = d_scale.z;
-                    gx[GC_MEAN] = d_mean.x, gx[GC_MEAN + 1] = d_mean.y, gx[GC_MEAN + 2] = d_mean.z;
-                    gx[GC_ROT] = d_rot0, gx[GC_ROT + 1] = d_rot1, gx[GC_ROT + 2] = d_rot2, gx[GC_ROT + 3] = d_rot3;
-                    gx[GC_RGB] = d_rgb.x, gx[GC_RGB + 1] = d_rgb.y, gx[GC_RGB + 2] = d_rgb.z, gx[GC_WEIGHT] = weight;
-                    gx[GC_NORMAL] = d_n.x, gx[GC_NORMAL + 1] = d_n.y, gx[GC_NORMAL + 2] = d_n.z;
-                    gx[GC_F0] = d_f0.x, gx[GC_F0 + 1] = d_f0.y, gx[GC_F0 + 2] = d_f0.z, gx[GC_ROUGH] = d_rough;
-                    bool mine = true; // this lane still owns a contribution
-                    if (PRIMARY) {
-                        // Primary tiles are coherent: the pixel to the right / below very often composites the SAME gaussian at the same
-                        // hit index. `ds_add_f32` retires about one lane per clock, so equal neighbours are summed in registers first
-                        // (two DPP levels: x neighbour, then y neighbour) and only the surviving lane touches the table.
-                        const unsigned long long em = __ballot(true);
-#define EGR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xF, 0xF, false)
-#define EGR_COMBINE(d, ctrl)                                                                                  \
-    {                                                                                                          \
-        const bool pact = ((em >> ((uint32_t)lane ^ (d))) & 1ull) != 0ull;                                     \
-        const uint32_t ppos = (uint32_t)EGR_DPP_I(pos, ctrl), pmine = (uint32_t)EGR_DPP_I(mine ? 1 : 0, ctrl); \
-        const bool same = pact && pmine != 0u && mine && ppos == pos;                                          \
-        const bool take = same && ((uint32_t)lane & (d)) == 0u;                                                \
-        _Pragma("unroll") for (int c = 0; c < EGR_GT_COMPS; c++) {                                             \
-            const float o = __int_as_float(EGR_DPP_I(__float_as_int(gx[c]), ctrl));                            \
-            gx[c] += take ? o : 0.0f;                                                                          \
-        }                                                                                                      \
-        if (same && !take) mine = false;                                                                       \
-    }
-                        EGR_COMBINE(1u, 0xB1)  // quad_perm [1,0,3,2]: lane ^ 1
-                        EGR_COMBINE(8u, 0x128) // row_ror 8: lane ^ 8
-#undef EGR_COMBINE
-#undef EGR_DPP_I
-                    }
-                    uint32_t slot = (pos * 2654435761u) >> 25; // top 7 bits -> [0,128); keyed by record index
-                    bool found = false;
-#pragma unroll 1
-                    for (int probe = 0; probe < (mine ? 8 : 0); probe++) {
-                        const uint32_t old = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, pos);
-                        if (old == EGR_GT_EMPTY || old == pos) { found = true; break; }
-                        slot = (slot + 1) & (EGR_GT_SLOTS - 1);
-                    }
-                    if (found) {
-                        new_slots += 1;
-#pragma unroll
-                        for (int c = 0; c < NC; c++) atomicAdd(&gt_vals[c * EGR_GT_SLOTS + slot], gx[c]);
-                    } else if (!mine) {
-                        // summed into a neighbour's contribution
-                    } else if (!bucketed) { // no buckets (primary step, or disabled): atomics on the gaussian's gradient row
-                        float *grow = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE;
-#pragma unroll
-                        for (int c = 0; c < EGR_GT_COMPS; c++)
-                            if (PRIMARY || c < GC_NORMAL) atomicAdd(grow + c, gx[c]);
-                    } else {
-                        direct = true, dpos = pos;
-                        dg[GC_OPA] = d_opacity, dg[GC_SCALE] = d_scale.x, dg[GC_SCALE + 1] = d_scale.y, dg[GC_SCALE + 2] = d_scale.z;
-                        dg[GC_MEAN] = d_mean.x, dg[GC_MEAN + 1] = d_mean.y, dg[GC_MEAN + 2] = d_mean.z;
-                        dg[GC_ROT] = d_rot0, dg[GC_ROT + 1] = d_rot1, dg[GC_ROT + 2] = d_rot2, dg[GC_ROT + 3] = d_rot3;
-                        dg[GC_RGB] = d_rgb.x, dg[GC_RGB + 1] = d_rgb.y, dg[GC_RGB + 2] = d_rgb.z, dg[GC_WEIGHT] = weight;
-                    }
-                }
-                if (!PRIMARY && __ballot(direct) != 0ull) { // table full for these gaussians (bucketed steps only)
-                    bool stored = false;
-                    { // straight to the bucket (one counter atomic per distinct bucket of the wave)
-                        const uint32_t at = bucket_alloc_wave(v, direct, dpos >> EGR_BUCKET_SHIFT, log_used);
-                        stored = direct && at < (v.log_mode ? v.log_cap : v.gb_cap); // full: atomics below (correct, slower)
-                        bucket_store_wave(v, stored, dpos, at, dg, stage);
-                    }
-                    if (direct && !stored) {
-                        float *grow = v.grad_rows + (size_t)dpos * EGR_ROW_STRIDE;
-#pragma unroll
-                        for (int c = 0; c < GC_NORMAL; c++) atomicAdd(grow + c, dg[c]);
-                    }
-                }
-            }
-            if (in_chain) blk = f2u(rows[0].x); // header: previous (older) block of this chain
-        }
-        (void)new_slots;
-        grad_table_flush<NC>(v, bucketed, gt_keys, gt_vals, stage, lane, log_used); // one flush per tile
+#include "backward_task.inc"
     }
     if (bucketed && v.log_mode && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
+}
+
+// The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
+// last bounce first, then the primary step (22 components, no records). Same per-step code as k_backward (backward_task.inc).
+__global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward_chain(DeviceView v) {
+    const int lane = threadIdx.x;
+    __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
+    __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
+    __shared__ float4 stage[4 * EGR_WAVE];
+    for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
+    for (int s = lane; s < EGR_GT_COMPS * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
+    __syncthreads();
+    const float exp_power = *v.cfg.exp_power;
+    const float eps_scale_grad = *v.cfg.eps_scale_grad;
+    const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
+    const egr_gaussians &g = v.g;
+    uint32_t cur_q = blockIdx.x & 7u;
+    const bool records = v.gb_data != nullptr;
+    uint32_t log_used = (records && v.log_mode) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u;
+
+    for (;;) {
+        const uint32_t tq = wave_next_task(v.queues + 8 * 3, v.task_count, cur_q);
+        if (tq == 0xFFFFFFFFu) break;
+        for (int step = num_bounces; step >= 1; step--) {
+            constexpr bool PRIMARY = false;
+            constexpr int NC = (int)GC_NORMAL;
+            const bool bucketed = records;
+            do {
+#include "backward_task.inc"
+            } while (false);
+        }
+        {
+            constexpr bool PRIMARY = true;
+            constexpr int NC = EGR_GT_COMPS;
+            const int step = 0;
+            const bool bucketed = false;
+            do {
+#include "backward_task.inc"
+            } while (false);
+        }
+    }
+    if (records && v.log_mode && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
 }
 
 // Second half of the bucketed bounce backward: one workgroup per bucket sums the bucket's records in LDS (ds_add_f32) and
@@ -1018,7 +832,16 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
                 egr_launch_step_epilogue(w, step, grads, ls);
                 egr_stamp_end(c, ls);
             }
-            if (grads) {
+            if (grads && chain) {
+                egr_stamp_begin(c, "backward_chain", ls);
+                hipLaunchKernelGGL(k_backward_chain, sgrid, block, 0, ls, w);
+                egr_stamp_end(c, ls);
+                if (w.gb_data && nbuckets && w.log_mode) {
+                    egr_stamp_begin(c, "backward_bucket_reduce", ls);
+                    hipLaunchKernelGGL(k_log_apply, dim3(c->num_slots), dim3(256), 0, ls, w);
+                    egr_stamp_end(c, ls);
+                }
+            } else if (grads) {
                 for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
                     egr_stamp_begin(c, bn[step], ls);
                     if (step == 0) hipLaunchKernelGGL(k_backward<true>, sgrid, block, 0, ls, w, step);
