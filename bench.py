@@ -219,7 +219,7 @@ def main():
         traffic = None
         try:
             rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_summary.json")))
-            if rounds and world == 1 and not a.forward_only:
+            if rounds and world == 1 and a.emulate_world <= 1 and not a.forward_only:
                 pm = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "pmc_summary.json"))).get(dom)
                 if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                     traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
