@@ -1,22 +1,28 @@
 // The hot path: __raygen__rg + __intersection__gaussian + forward_pass + backward_pass of the reference
 // (shaders.cu:9-173, forward_pass.cu:3-155, backward_pass.cu:3-222) as hand-written HIP kernels for gfx950.
 //
-// Structure (MI355X-first; nothing here is a translation of the OptiX pipeline):
-//   * one wave64 = one 8x8 pixel tile, one lane = one ray; PERSISTENT waves pull tiles from an atomic queue
+// Structure (MI355X-first; nothing here is a translation of the OptiX pipeline; DESIGN.md 4 has the measurements):
+//   * one wave64 = one 8x8 pixel tile, one lane = one ray; PERSISTENT waves pull tiles from 8 XCD-affine atomic queues
 //     (ragged per-ray work: 1..1000s of candidates), one workgroup = one wave so waves never wait on each other;
-//   * the path is split per bounce step (k_forward<step>), not fused into one megakernel: per-ray state lives in
-//     a task-linear SoA buffer (fully coalesced), registers stay low, occupancy high;
-//   * traversal of the threaded pre-order LBVH is STACKLESS (hit -> node+1, miss -> skip), "while-while":
-//     every lane first advances to its next leaf, then all lanes evaluate their candidate together;
-//   * the reference's global per-pixel linked list (one same-address atomic per candidate, 36 B entries,
-//     pointer chasing) is replaced by a per-resident-wave candidate scratch, lane-interleaved [k][lane] so
-//     every access of the wave is one contiguous 256-B row; it is reused tile after tile and stays in L2/MALL;
-//   * depth ordering = repeated strict-successor selection over the (coalesced) key rows; semantically the
-//     reference's 16-at-a-time k-buffer (forward_pass.cu:55-137) without its batch-boundary tie drop;
-//   * composited hits needed by the backward pass go to an arena in 8-row blocks (one atomic per 8 rows per
-//     WAVE instead of one per hit per lane), chained newest->oldest, which is the order backward walks;
-//   * backward recomputes the local hit point from the snapshot transform instead of storing it (it needs W
-//     and M anyway), then issues the same 15/22 float atomics per hit as backward_pass.cu:210-220.
+//   * a tile runs through ALL its steps in one go (k_forward_chain: trace, step epilogue, trace, ...; k_backward_chain), so
+//     a launch pays the tail of its heaviest tile once per chain, not once per step. The per-step source lives in
+//     forward_task.inc / backward_task.inc / egr_epilogue.hpp and is also built as one kernel per step (k_forward,
+//     k_step_epilogue, k_backward; EGR_CHAIN=0). Per-ray state lives in a task-linear SoA buffer (fully coalesced);
+//   * the 8-wide BVH (128-B line-sized nodes, 16-bit child boxes) is walked as ONE packet by coherent tiles (primary rays:
+//     scalar loads, every lane tests its own ray) and by GROUPS OF EIGHT LANES PER RAY by incoherent tiles (lane m tests
+//     child m; ballot compaction onto a per-ray LDS stack and leaf queue; groups take rays from a shared per-tile list);
+//     traversal (phase A) and candidate evaluation (phase B) are decoupled;
+//   * the reference's global per-pixel linked list (one same-address atomic per candidate, 36 B entries, pointer chasing)
+//     is replaced by a per-resident-wave candidate scratch, one contiguous run per lane ([lane][k]) with bump-allocated
+//     extension blocks for the rare long list; it is reused tile after tile;
+//   * depth ordering = strict-successor selection in batches of 8 (sorted insertion in registers, stable on ties);
+//     semantically the reference's 16-at-a-time k-buffer (forward_pass.cu:55-137) without its batch-boundary tie drop;
+//   * composited hits needed by the backward pass go to an arena in 8-row blocks (one atomic per 8 rows per WAVE instead
+//     of one per hit per lane), chained newest->oldest, which is the order backward walks;
+//   * backward recomputes the local hit point from the snapshot transform instead of storing it, sums a tile's
+//     contributions per gaussian in an LDS hash table (DPP neighbour pre-reduction for primary rays) and sends what does
+//     not fit as 64-B records to per-wave logs that k_log_apply adds to position-ordered gradient rows (one 64-B atomic
+//     request per record); k_grad_gather scatters the rows to the reference's gradient tensors.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
