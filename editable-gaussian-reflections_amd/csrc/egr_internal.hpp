@@ -184,7 +184,7 @@ struct egr_context {
     int morton_size_period = 0; // 0: plain Morton order; k > 0: one size bit after every k xyz triples; < 0: size bit first (s x y z)
     // strands: the rank's tiles are cut into `strands` slices whose kernel sequences run on separate HIP streams, so one
     // slice's persistent-wave tail (few long tiles left) is filled by the other slice's next kernel
-    int strands = 2;        // allocated (scratch, streams)
+    int strands = 3;        // allocated (scratch, streams); 3 strands + the caller's stream = the 4 HW queues of the runtime
     int strands_active = 0; // used by the next launch (0 = all allocated)
     hipStream_t strand_stream[EGR_MAX_STRANDS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[EGR_MAX_STRANDS] = {};
