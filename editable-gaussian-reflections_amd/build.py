@@ -29,7 +29,7 @@ if os.environ.get("EGR_TRAVERSAL_STATS"):
     HIP_FLAGS.append("-DEGR_TRAVERSAL_STATS=1")
 HIP_SOURCES = ["trace.hip", "epilogue.hip", "bvh.hip", "api.hip", "knn.hip", "step.hip", "denoise.hip"]
 EXTRA_FLAGS = {"epilogue.hip": ["-ffp-contract=off"]}  # see the note at the top of csrc/epilogue.hip
-HEADERS = [os.path.join(CSRC, "egr_internal.hpp"), os.path.join(CSRC, "egr_device.hpp"), os.path.join(CSRC, "egr_state.hpp"), os.path.join(ROOT, "include", "egr_raytracer.h")]
+HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join(ROOT, "include", "egr_raytracer.h")]  # every object depends on all of them
 
 
 def _newer(target, deps):
