@@ -69,6 +69,8 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     if (const char *e = getenv("EGR_BVH_BUILDER")) c->bvh_builder = atoi(e);
     if (const char *e = getenv("EGR_COLLAPSE_ABSORB")) c->collapse_absorb = atoi(e);
     if (const char *e = getenv("EGR_GROUP_WALK")) c->group_walk = atoi(e);
+    if (const char *e = getenv("EGR_BOUNCE_TABLE")) c->bounce_table = atoi(e);
+    if (const char *e = getenv("EGR_WIDE_PRIMARY")) c->wide_primary = atoi(e);
     if (const char *e = getenv("EGR_SPLIT")) c->split_mode = atoi(e);
     if (const char *e = getenv("EGR_CHAIN")) c->chain_mode = atoi(e);
     if (const char *e = getenv("EGR_CHAIN_BELOW")) c->chain_below = atof(e);

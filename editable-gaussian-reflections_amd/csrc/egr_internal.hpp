@@ -99,6 +99,8 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t task_begin, task_count; // this strand's slice of the rank's task order (see egr_trace_launch)
     uint32_t *queues;      // [strands][6 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
+    int wide_primary;      // 1: the primary step's table flush adds rows as 16-lane records too (EGR_WIDE_PRIMARY)
+    int bounce_table;      // 0: bounce-step hits skip the LDS table and go out as records (experiment, EGR_BOUNCE_TABLE)
     int log_mode;          // bounce-step records go to one launch-wide log instead of per-gaussian-block buckets
     uint32_t log_cap;      // log mode: records per resident wave slot
     uint32_t log_slot0;    // log mode: first wave slot of this strand
@@ -168,7 +170,9 @@ struct egr_context {
     uint32_t *cand_queue = nullptr, *stack_spill = nullptr;
     float4 *gb_data = nullptr;
     uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
-    int bucketed_backward = 2; // bounce-step backward: 0 atomics on the gradient rows, 1 per-block buckets + counting-sort reduce, 2 per-wave record logs + apply
+    int bounce_table = 0;      // 1: bounce-step hits are pre-summed per tile in the LDS table before they leave the wave (EGR_BOUNCE_TABLE)
+    int wide_primary = 1;      // 1: the primary step's table flush adds rows as two 16-lane records (EGR_WIDE_PRIMARY)
+    int bucketed_backward = 3; // bounce-step backward: 3 records added to the gradient rows by 16 lanes each, in the kernel (default); 2 per-wave record logs + k_log_apply; 1 per-block buckets + counting-sort reduce; 0 scalar atomics per hit (EGR_BUCKETED_BACKWARD)
     int group_walk = 1;
     int chain_mode = 1;       // fused per-tile chains (k_forward_chain, k_backward_chain): 1 always (default), 0 never (step-by-step kernels), -1 only with few tiles per wave slot (EGR_CHAIN)
     double chain_below = 4.0; // auto: chain when a strand has fewer tiles than this many per wave slot (EGR_CHAIN_BELOW)

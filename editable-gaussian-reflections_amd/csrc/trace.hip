@@ -322,6 +322,10 @@ EGR_DI uint32_t bucket_alloc_wave(const DeviceView &v, bool need, uint32_t bucke
     const int lane = threadIdx.x;
     unsigned long long M = __ballot(need);
     const unsigned long long below = (1ull << lane) - 1ull;
+    if (v.log_mode == 2) { // records go straight to the gradient rows (bucket_store_wave): nothing to allocate, only counted
+        log_used += (uint32_t)__popcll(M);
+        return need ? 0u : 0xFFFFFFFFu;
+    }
     if (v.log_mode) { // every resident wave owns a private run of the record log: no allocation atomics at all
         const uint32_t at = log_used + (uint32_t)__popcll(M & below);
         log_used += (uint32_t)__popcll(M);
@@ -340,11 +344,40 @@ EGR_DI uint32_t bucket_alloc_wave(const DeviceView &v, bool need, uint32_t bucke
     const uint32_t base = (uint32_t)__shfl((int)base_mine, (int)my_leader);
     return need ? base + my_rank : 0xFFFFFFFFu;
 }
+// Direct mode: SIXTEEN LANES PER RECORD add the 15 values of every lane with `ok` to components base .. base+14 of its gaussian's
+// gradient row - one 64-B atomic request per record, nothing returned, so the requests drain behind the wave's arithmetic
+// instead of in a kernel of their own (a lane adding its own 15 values issues 15 x 64 scattered 4-B requests per instruction
+// row). Wave-uniform call; `stage` = 64 x 4 float4.
+EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const float (&r)[15], uint32_t base, float4 *stage) {
+    const int lane = threadIdx.x;
+    if (ok) {
+        stage[4 * lane + 0] = make_float4(u2f(pos), r[0], r[1], r[2]);
+        stage[4 * lane + 1] = make_float4(r[3], r[4], r[5], r[6]);
+        stage[4 * lane + 2] = make_float4(r[7], r[8], r[9], r[10]);
+        stage[4 * lane + 3] = make_float4(r[11], r[12], r[13], r[14]);
+    }
+    const unsigned long long okm = __ballot(ok);
+    __syncthreads();
+    const float *sf = reinterpret_cast<const float *>(stage);
+#pragma unroll 4
+    for (int pass = 0; pass < 16; pass++) {
+        const int src = 4 * pass + (lane >> 4), c = lane & 15;
+        if (((okm >> (4 * pass)) & 0xFull) == 0ull) continue; // wave-uniform: none of these four records exists
+        const float x = sf[16 * src + c];
+        const uint32_t p = f2u(sf[16 * src]);
+        if (((okm >> src) & 1ull) && c != 0 && x != 0.0f) atomicAdd(v.grad_rows + (size_t)p * EGR_ROW_STRIDE + base + (uint32_t)(c - 1), x);
+    }
+    __syncthreads();
+}
 // Writes the records of the lanes with `ok` to their bucket slots, FOUR LANES PER RECORD: a lane stages its 64-B record in LDS,
 // then in each of four passes lane L stores quarter (L & 3) of the record of lane 16 * pass + (L >> 2) - one contiguous 64-B
 // request per record instead of four 16-B requests from one lane (the write-through L1 forwards every store instruction of a
 // lane as its own L2 request, and L2 requests are what bounds the bounce backward). Wave-uniform call; `stage` = 64 x 4 float4.
 EGR_DI void bucket_store_wave(const DeviceView &v, bool ok, uint32_t pos, uint32_t at, const float (&r)[15], float4 *stage) {
+    if (v.log_mode == 2) { // GC_OPA .. GC_WEIGHT are components 0..14 of the row, in record order
+        wide_add_wave(v, ok, pos, r, 0u, stage);
+        return;
+    }
     const int lane = threadIdx.x;
     if (ok) {
         stage[4 * lane + 0] = make_float4(u2f(v.log_mode ? pos : (pos & ((1u << EGR_BUCKET_SHIFT) - 1u))), r[GC_OPA], r[GC_SCALE], r[GC_SCALE + 1]);
@@ -381,6 +414,16 @@ template <int NC> EGR_DI void grad_table_flush(const DeviceView &v, bool buckete
                 bucket_store_wave(v, stored, pos, at, x, stage);
             }
         }
+        if constexpr (NC == EGR_GT_COMPS) { // primary step: the row's 22 components as two 16-lane records
+            if (v.log_mode == 2 && v.wide_primary && __ballot(valid) != 0ull) {
+                float lo[15], hi[15];
+#pragma unroll
+                for (int c = 0; c < 15; c++) lo[c] = x[c], hi[c] = (15 + c < NC) ? x[(15 + c < NC) ? 15 + c : 0] : 0.0f;
+                wide_add_wave(v, valid, pos, lo, 0u, stage);
+                wide_add_wave(v, valid, pos, hi, 15u, stage);
+                stored = valid;
+            }
+        }
         if (valid && !stored) {
             float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all components of a gaussian share one line
 #pragma unroll
@@ -399,7 +442,7 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
     constexpr int NC = PRIMARY ? EGR_GT_COMPS : (int)GC_NORMAL; // gradient components of this instantiation (22 / 15)
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
     __shared__ float gt_vals[NC * EGR_GT_SLOTS];
-    __shared__ float4 stage[PRIMARY ? 1 : 4 * EGR_WAVE]; // bucket records on their way out (bucket_store_wave)
+    __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (bucket_store_wave / wide_add_wave)
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < NC * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
     __syncthreads();
@@ -410,14 +453,15 @@ template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute_
     const egr_gaussians &g = v.g;
     uint32_t cur_q = blockIdx.x & 7u;
     const bool bucketed = !PRIMARY && v.gb_data != nullptr;
-    uint32_t log_used = (bucketed && v.log_mode) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u; // records this wave slot has logged so far
+    uint32_t log_used = (bucketed && v.log_mode == 1) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u; // records this wave slot has logged so far
 
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8 * (3 + step), v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
 #include "backward_task.inc"
     }
-    if (bucketed && v.log_mode && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
+    if (bucketed && v.log_mode == 1 && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
+    if (bucketed && v.log_mode == 2 && lane == 0 && log_used) atomicAdd(v.control + CW_BUCKET_RECORDS, log_used);
 }
 
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
@@ -436,7 +480,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
     const egr_gaussians &g = v.g;
     uint32_t cur_q = blockIdx.x & 7u;
     const bool records = v.gb_data != nullptr;
-    uint32_t log_used = (records && v.log_mode) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u;
+    uint32_t log_used = (records && v.log_mode == 1) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u;
 
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8 * 3, v.task_count, cur_q);
@@ -459,7 +503,8 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3
             } while (false);
         }
     }
-    if (records && v.log_mode && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
+    if (records && v.log_mode == 1 && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
+    if (records && v.log_mode == 2 && lane == 0 && log_used) atomicAdd(v.control + CW_BUCKET_RECORDS, log_used);
 }
 
 // Second half of the bucketed bounce backward: one workgroup per bucket sums the bucket's records in LDS (ds_add_f32) and
@@ -774,9 +819,11 @@ DeviceView egr_make_view(const egr_context *c) {
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
     v.group_walk = c->group_walk;
+    v.bounce_table = c->bounce_table;
+    v.wide_primary = c->wide_primary;
     v.split_mask = 0u;
     v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
-    v.log_mode = c->bucketed_backward == 2, v.log_slot0 = 0;
+    v.log_mode = c->bucketed_backward == 2 ? 1 : c->bucketed_backward == 3 ? 2 : 0, v.log_slot0 = 0; // 1: per-wave logs + k_log_apply, 2: direct
     v.log_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->gb_buckets_alloc * c->gb_cap / std::max<uint64_t>((uint64_t)c->num_slots * (uint64_t)c->strands, 1), 1u << 24);
     return v;
 }
@@ -842,7 +889,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
                 egr_stamp_begin(c, "backward_chain", ls);
                 hipLaunchKernelGGL(k_backward_chain, sgrid, block, 0, ls, w);
                 egr_stamp_end(c, ls);
-                if (w.gb_data && nbuckets && w.log_mode) {
+                if (w.gb_data && nbuckets && w.log_mode == 1) {
                     egr_stamp_begin(c, "backward_bucket_reduce", ls);
                     hipLaunchKernelGGL(k_log_apply, dim3(c->num_slots), dim3(256), 0, ls, w);
                     egr_stamp_end(c, ls);
@@ -853,7 +900,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
                     if (step == 0) hipLaunchKernelGGL(k_backward<true>, sgrid, block, 0, ls, w, step);
                     else hipLaunchKernelGGL(k_backward<false>, sgrid, block, 0, ls, w, step);
                     egr_stamp_end(c, ls);
-                    if (step == 1 && w.gb_data && nbuckets && w.log_mode) {
+                    if (step == 1 && w.gb_data && nbuckets && w.log_mode == 1) {
                         // the strand's bounce records are complete: apply them now, on the strand's stream - the kernel is bound by
                         // atomic requests, not by the CUs, and overlaps with the other strand's kernels
                         egr_stamp_begin(c, "backward_bucket_reduce", ls);

@@ -601,7 +601,7 @@ def test_full_size_gradient_paths_agree(ren, orc, syn, monkeypatch):
     cam = syn.default_camera()
     tg = syn.make_targets(W, H)
     grads = []
-    for bucketed in ("2", "1", "0"):  # per-wave record logs (default), per-block buckets, plain atomics
+    for bucketed in ("2", "1", "0", "3"):  # per-wave record logs, per-block buckets, plain atomics, records added directly (16 lanes each)
         monkeypatch.setenv("EGR_BUCKETED_BACKWARD", bucketed)
         rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000)
         run_grad(ren, rt, cam_obj(ren, cam, tg))
@@ -613,4 +613,5 @@ def test_full_size_gradient_paths_agree(ren, orc, syn, monkeypatch):
     scale = float(grads[2].abs().max())
     assert float((grads[0] - grads[2]).abs().max()) < 1e-5 * scale
     assert float((grads[1] - grads[2]).abs().max()) < 1e-5 * scale
+    assert float((grads[3] - grads[2]).abs().max()) < 1e-5 * scale
 
