@@ -230,7 +230,7 @@ def main():
                 "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
                 "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
                 "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
-                "strands_timed_region": a.strands if a.strands > 0 else int(os.environ.get("EGR_STRANDS", 3)), "strands_profile_pass": 1,
+                "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
                 "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
 
     if rank == 0:

@@ -847,7 +847,10 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
         // step kernels in order on its own stream. Tiles only depend on their own earlier steps, so strands never synchronise
         // with each other until the join; while one strand's kernel drains its last long tiles the next kernel of another
         // strand takes the freed wave slots.
-        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : c->strands;
+        // (no explicit egr_set_strands: all strands when the rank has at least four tiles per wave slot; with fewer - a rank of a
+        // multi-GPU partition - concurrent chains only delay each other's heaviest tiles: 4.66 / 4.85 / 4.97 ms with 1 / 2 / 3
+        // strands for rank 0 of an 8-way partition, 18.7 / 18.3 / 18.0 ms for the whole image)
+        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : ((uint64_t)v.num_tasks >= 4ull * c->num_slots ? c->strands : 1);
         const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
         if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
         for (int st = 0; st < S; st++) {
