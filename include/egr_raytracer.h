@@ -151,7 +151,8 @@ int egr_set_partition(egr_context *ctx, int rank, int world_size);
 /* Strands (not in the reference): egr_raytrace cuts this context's tiles into `strands` slices and runs their step kernels on
  * separate internal HIP streams (forked from / joined to the caller's stream), so that one slice's persistent-wave tail is
  * filled by another slice's next kernel. 1 = everything on the caller's stream (per-kernel timings are then exclusive).
- * Accepts 1..(value at creation: env EGR_STRANDS, default 2); returns 1 otherwise. */
+ * Accepts 1..(value at creation: env EGR_STRANDS, default 3); returns 1 otherwise. Without a call, a launch uses all strands
+ * when the rank has at least four tiles per resident wave slot and one strand below that (multi-GPU partitions). */
 int egr_set_strands(egr_context *ctx, int strands);
 
 /* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace. */
