@@ -19,10 +19,11 @@
 //     semantically the reference's 16-at-a-time k-buffer (forward_pass.cu:55-137) without its batch-boundary tie drop;
 //   * composited hits needed by the backward pass go to an arena in 8-row blocks (one atomic per 8 rows per WAVE instead
 //     of one per hit per lane), chained newest->oldest, which is the order backward walks;
-//   * backward recomputes the local hit point from the snapshot transform instead of storing it, sums a tile's
-//     contributions per gaussian in an LDS hash table (DPP neighbour pre-reduction for primary rays) and sends what does
-//     not fit as 64-B records to per-wave logs that k_log_apply adds to position-ordered gradient rows (one 64-B atomic
-//     request per record); k_grad_gather scatters the rows to the reference's gradient tensors.
+//   * backward recomputes the local hit point from the snapshot transform instead of storing it. Primary tiles sum their
+//     contributions per gaussian in an LDS hash table (DPP neighbour pre-reduction first); whatever leaves the wave - a
+//     bounce hit, a flushed table slot - is added to its gaussian's position-ordered gradient row by SIXTEEN LANES PER
+//     RECORD (one 64-B non-returning atomic request instead of 15 scattered ones; wide_add_wave); k_grad_gather scatters
+//     the rows to the reference's gradient tensors. (EGR_BUCKETED_BACKWARD = 2 / 1 / 0 keep the earlier record paths.)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
