@@ -761,7 +761,7 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->ext_vals, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float2)));
     EGR_HIP(hipMalloc((void **)&c->stack_spill, S * c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
     double bwd_bytes = (double)c->bwd_capacity * 36.0;
-    if (c->bucketed_backward) bwd_bytes *= 0.25; // the rest holds the gradient buckets
+    if (c->bucketed_backward == 1 || c->bucketed_backward == 2) bwd_bytes *= 0.25; // the rest holds the gradient buckets / record logs (mode 3 stores no records)
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
     EGR_HIP(hipMalloc((void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
@@ -793,7 +793,7 @@ void egr_trace_reserve_buckets(egr_context *c, uint32_t n) {
     if (nb <= c->gb_buckets_alloc && c->gb_data) return;
     dfree(c->gb_data), dfree(c->gb_count);
     const uint32_t nb_alloc = nb + nb / 8 + 1;
-    const double bytes = (double)c->bwd_capacity * 36.0 * 0.75;
+    const double bytes = c->bucketed_backward == 3 ? 0.0 : (double)c->bwd_capacity * 36.0 * 0.75; // mode 3 adds records to the rows directly: a token allocation
     uint64_t cap = (uint64_t)(bytes / 64.0 / (double)nb_alloc);
     c->gb_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 1u << 22);
     EGR_HIP(hipMalloc((void **)&c->gb_data, (size_t)nb_alloc * c->gb_cap * 64));
@@ -826,6 +826,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
     v.log_mode = c->bucketed_backward == 2 ? 1 : c->bucketed_backward == 3 ? 2 : 0, v.log_slot0 = 0; // 1: per-wave logs + k_log_apply, 2: direct
     v.log_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->gb_buckets_alloc * c->gb_cap / std::max<uint64_t>((uint64_t)c->num_slots * (uint64_t)c->strands, 1), 1u << 24);
+    if (v.log_mode == 2) v.log_cap = std::max(v.log_cap, 1u); // (nothing is stored in this mode; a record is `stored` when at = 0 < log_cap)
     return v;
 }
 
