@@ -269,7 +269,7 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(Devi
 // tiles). The launch path uses it when a rank holds few tiles per wave slot (multi-GPU partitions): every step kernel then
 // lasts as long as its heaviest tile, and a tile's cost at one step says nothing about its cost at the next.
 // Same per-step code as k_forward (forward_task.inc) and the same step epilogue as k_step_epilogue (egr_epilogue.hpp).
-template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_forward_chain(DeviceView v) {
+template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) k_forward_chain(DeviceView v) {
 #include "forward_decl.inc"
     __shared__ uint32_t wc[3 * EGR_NSTEPS]; // this wave's ray / candidate / composited counts per step
     if (lane < 3 * EGR_NSTEPS) wc[lane] = 0u;
@@ -743,7 +743,9 @@ void egr_trace_alloc(egr_context *c) {
     int per_cu_g = 0, per_cu_n = 0;
     EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, k_forward<true>, EGR_WAVE, 0));
     EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_n, k_forward<false>, EGR_WAVE, 0));
-    int per_cu = std::max(1, std::min(32, std::max(per_cu_g, per_cu_n)));
+    int per_cu_c = 0; // the chain kernels are built for four waves per SIMD (they are faster with more waves in flight even with spills)
+    if (c->chain_mode != 0) EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_forward_chain<true>, EGR_WAVE, 0));
+    int per_cu = std::max(1, std::min(32, std::max(std::max(per_cu_g, per_cu_n), per_cu_c)));
     if (const char *e = getenv("EGR_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // tuning knob
     uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
