@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="480x270")
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
-    p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default, 2); the per-kernel profile pass always uses 1")
+    p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 3 from four tiles per wave slot, else 1); the per-kernel profile pass always uses 1")
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
     p.add_argument("--forward-only", action="store_true", help="config B: no-grad render instead of a training iteration")
     return p.parse_args()
