@@ -6,12 +6,13 @@ One "step" = one training-iteration pass of the hot path behind the reference's 
 LBVH refit), raytrace (forward + in-kernel loss gradient + backward), gradient all-reduce over ranks, gradient
 import). A "ray" = one (pixel, bounce-step) traversal; rays/step come from the kernels' own counters.
 
-  python bench.py                       # 1 GPU, defaults finish in a few minutes
+  python bench.py                       # config C, 1 GPU: the trained-like cloud (headline) and the literal dense-init cloud
+  python bench.py --config B            # BASELINE config 2: 100k Gaussians, 1080p, forward only (measure_fps.py protocol)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: the image is split into 16x16-pixel tiles dealt round-robin to the ranks (the scene and the BVH are
-replicated), gradients are summed with ONE RCCL all-reduce of the flat [22N] buffer -> "scaling": "strong".
+replicated), THIS launch's gradients are summed with ONE RCCL all-reduce of a flat [22N] buffer -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -26,6 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+ROUND = "r2"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh)
 
 
 def parse():
@@ -33,18 +35,27 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=50)  # ~1.5 s of load: the core clock needs about that long to ramp (measured)
+    p.add_argument("--config", default="C", choices=["B", "C"], help="BASELINE.json config: C = 1M Gaussians forward+backward (metric), B = 100k forward only")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--gaussians", type=int, default=1_000_000)
-    p.add_argument("--variant", default="trained", choices=["trained", "init"])
+    p.add_argument("--gaussians", type=int, default=None)
+    p.add_argument("--variant", default=None, choices=["trained", "init"], help="opacity of the synthetic cloud: trained-like 0.8 (bounces happen) or the literal dense-init 0.1 (config.py:44)")
+    p.add_argument("--no-second-variant", action="store_true", help="config C at N=1 also times the other opacity variant (reported in `other_variant`); skip it")
     p.add_argument("--bounces", type=int, default=2)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="480x270")
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
     p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 3 from four tiles per wave slot, else 1); the per-kernel profile pass always uses 1")
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
-    p.add_argument("--forward-only", action="store_true", help="config B: no-grad render instead of a training iteration")
-    return p.parse_args()
+    p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
+    a = p.parse_args()
+    if a.config == "B":
+        a.forward_only = True
+    if a.gaussians is None:
+        a.gaussians = 100_000 if a.config == "B" else 1_000_000
+    if a.variant is None:
+        a.variant = "init" if a.config == "B" else "trained"
+    return a
 
 
 def algorithmic_bytes(kind, step, rays, hc, kc, pixels):
@@ -70,11 +81,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     local_rank = local_rank % torch.cuda.device_count()
+    dist = None
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" IS RCCL on ROCm. EGR_DIST_BACKEND=gloo only exists to exercise this code path with 2 ranks on ONE GPU.
+        # "nccl" IS RCCL on ROCm. EGR_DIST_BACKEND=gloo only exists to exercise this code path with 2 ranks on ONE GPU (tests/).
         backend = os.environ.get("EGR_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -82,169 +95,186 @@ def main():
             dist.init_process_group(backend)
     syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic")
     ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
-
     W, H, N = a.width, a.height, a.gaussians
-    g = syn.make_scene(N, a.variant, seed=0)
     cam = syn.default_camera()
     tg = syn.make_targets(W, H)
-    pc = ren.GaussianParams(g)
-    # capacities: same meaning as the reference's ppll sizes (entries of 36 B); its own test uses 300M/200M at 1536x1024
-    rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000, rank=rank, world_size=world)
-    m = rt.cuda_module
-    m.get_config().num_bounces.fill_(a.bounces)
-    if a.strands > 0:
-        m.set_strands(a.strands)
-    if a.emulate_world > 1:
-        assert world == 1
-        m.set_partition(0, a.emulate_world)
     images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()}
     camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **images)
-
-    def one_step():
-        if a.forward_only:
-            with torch.no_grad():
-                rt(camera)
-        else:
-            rt.zero_grad()
-            rt(camera, target_diffuse=images["diffuse_image"], target_specular=images["specular_image"], target_depth=images["depth_image"],
-               target_normal=images["normal_image"], target_roughness=images["roughness_image"], target_f0=images["f0_image"])
+    dbg = (lambda *x: print(f"[rank {rank}]", *x, file=sys.stderr, flush=True)) if os.environ.get("EGR_BENCH_VERBOSE") else (lambda *x: None)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    dbg = (lambda *x: print(f"[rank {rank}]", *x, file=sys.stderr, flush=True)) if os.environ.get("EGR_BENCH_VERBOSE") else (lambda *x: None)
-    dbg("setup done, tasks", m.get_counters()[10])
-    for _ in range(a.warmup):
-        one_step()
-        dbg("warmup step done")
-    barrier()
-    m.reset_lifetime_counters()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    c = m.get_counters()
-    status = c[11]
-    life_rays = c[9]
-    tt = torch.tensor([dt, float(life_rays)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = tt.clone()
+    def reduce_pair(dt, rays):  # max time / summed rays over ranks (host tensors with gloo, device tensors with RCCL)
+        if world == 1:
+            return dt, rays
+        dev = "cuda" if backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tsum = torch.tensor([rays], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, total_rays = float(tmax[0]), float(tsum[1])
-    else:
-        total_rays = float(life_rays)
-    ms_per_step = dt / a.steps * 1e3
-    value = total_rays / dt / 1e6
+        return float(tmax[0]), float(tsum[0])
 
-    cpu = None
-    hc_ref_per_ray = None  # reference-defined candidates per ray (cube overlaps) measured by the oracle sample
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (the other ranks would sit in the next collective meanwhile)
-        from oracle import oracle as orc
+    def run_variant(variant, with_profile, with_cpu):
+        """Times `steps` passes of the hot path on the `variant` cloud; returns the pieces of the JSON line."""
+        g = syn.make_scene(N, variant, seed=0)
+        pc = ren.GaussianParams(g)
+        # capacities: same meaning as the reference's ppll sizes (entries of 36 B); its own test uses 300M/200M at 1536x1024
+        rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000, rank=rank, world_size=world)
+        m = rt.cuda_module
+        m.get_config().num_bounces.fill_(a.bounces)
+        if a.strands > 0:
+            m.set_strands(a.strands)
+        if a.emulate_world > 1:
+            assert world == 1
+            m.set_partition(0, a.emulate_world)
 
-        cw, ch = (int(x) for x in a.cpu_sample.split("x"))
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        o = orc.Oracle(cw, ch, threads=cores)
-        o.set_camera(cam["origin"], cam["c2w"], cam["fov"])
-        o.set_config(num_bounces=a.bounces, **syn.TRAIN_LOSS_WEIGHTS)
-        o.set_gaussians(g)
-        o.update_bvh()
-        ctg = syn.make_targets(cw, ch)
-        o.raytrace(not a.forward_only, targets=ctg)  # warm-up
-        t1 = time.perf_counter()
-        reps = 2
-        nr = 0
-        for _ in range(reps):
-            o.update_bvh()
-            out = o.raytrace(not a.forward_only, targets=ctg)
-            nr += int(out["effective_steps"].sum())
-        t_cpu = time.perf_counter() - t1
-        hc_ref_per_ray = float(out["num_traversed"].sum()) / max(float(out["effective_steps"].sum()), 1.0)
-        cpu = {"value": round(nr / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": f"CPU restatement of the reference algorithm (oracle/), same scene+camera+config at {cw}x{ch}, "
-                         f"{'forward' if a.forward_only else 'update_bvh + forward+backward'}, {reps} reps, OpenMP over rows"}
+        def one_step():
+            if a.forward_only:
+                with torch.no_grad():
+                    rt(camera)  # measure_fps.py:27-52: render under no_grad, no BVH update between frames
+            else:
+                rt.zero_grad()
+                rt(camera, target_diffuse=images["diffuse_image"], target_specular=images["specular_image"], target_depth=images["depth_image"],
+                   target_normal=images["normal_image"], target_roughness=images["roughness_image"], target_f0=images["f0_image"])
 
-    # ---- per-kernel timing pass (HIP events on the launch stream, untimed region) -> roofline of the dominant kernel
-    roof = None
-    kern = {}
-    acc = {}
-    # the profile pass runs the kernels one at a time (strands = 1): a kernel's duration is then its exclusive time on the GPU
-    m.set_strands(1)
-    for _ in range(min(a.warmup, 30) if a.profile_steps > 0 else 0):  # the CPU baseline above left the GPU idle: ramp the clocks again
-        one_step()
-    m.enable_timing(rank == 0)
-    for _ in range(a.profile_steps):  # every rank runs these steps (they contain the all-reduce); rank 0 reads the stamps
-        one_step()
-        torch.cuda.synchronize()
-        if rank == 0:
-            for name, ms in m.last_kernel_ms():
-                acc.setdefault(name, []).append(ms)
-            acc.setdefault("update_bvh", []).append(m.last_update_bvh_ms())
-            acc.setdefault("raytrace_total", []).append(m.last_raytrace_ms())
-    m.enable_timing(False)
-    barrier()
-    if rank == 0 and a.profile_steps > 0:
-        kern = {k: float(np.median(v)) for k, v in acc.items() if v and v[0] >= 0}
-        cc = m.get_counters()
-        rays, cand, comp = cc[0:3], list(cc[3:6]), cc[6:9]
-        pixels_rank = rays[0]
-        # Hc of SURVEY 8d = gaussians whose CUBE the segment overlaps (what the reference's intersection program is invoked
-        # for). The HIP tree bounds ellipsoids and evaluates fewer; the algorithmic bytes keep the reference definition:
-        # the kernels' own counters are scaled to the oracle-measured candidates per ray when the CPU sample ran.
-        hc_scale = 1.0
-        if hc_ref_per_ray is not None and sum(cand) > 0:
-            hc_scale = max(1.0, hc_ref_per_ray * sum(rays) / float(sum(cand)))
-        cand_eval = list(cand)
-        cand = [c * hc_scale for c in cand]
-        cands = {}
-        for s in range(3):
-            kind = "forward_nograd" if a.forward_only else "forward"
-            cands[f"forward_step{s}"] = algorithmic_bytes(kind, s, rays[s], cand[s], comp[s], pixels_rank)
+        dbg("setup done", variant)
+        for _ in range(a.warmup):
+            one_step()
+        barrier()
+        m.reset_lifetime_counters()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        c = m.get_counters()
+        res = {"status": int(c[11])}
+        dt, total_rays = reduce_pair(dt, float(c[9]))
+        res["ms_per_step"] = dt / a.steps * 1e3
+        res["value"] = total_rays / dt / 1e6
+
+        cpu = None
+        if with_cpu and rank == 0 and world == 1:  # reported at N=1 only (the other ranks would sit in the next collective meanwhile)
+            from oracle import oracle as orc
+
+            cw, ch = (int(x) for x in a.cpu_sample.split("x"))
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            o = orc.Oracle(cw, ch, threads=cores)
+            o.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+            o.set_config(num_bounces=a.bounces, **syn.TRAIN_LOSS_WEIGHTS)
+            o.set_gaussians(g)
+            o.update_bvh()  # the build (rebuild_bvh); the timed reps refit like the reference's per-iteration update
+            ctg = syn.make_targets(cw, ch)
+            gshape = {"dL_drgb": 3, "dL_dnormal": 3, "dL_df0": 3, "dL_droughness": 1, "dL_dopacity": 1, "dL_dscale": 3, "dL_dmean": 3, "dL_drotation": 4, "total_weight": 1}
+            gbuf = {k: np.zeros((N, w), np.float64) for k, w in gshape.items()}  # the caller's gradient tensors, allocated once
+            o.raytrace(not a.forward_only, targets=ctg, grads_into=gbuf)  # warm-up
+            rates, t_start = [], time.perf_counter()
+            while len(rates) < 5 or (time.perf_counter() - t_start < 10.0 and len(rates) < 25):
+                t1 = time.perf_counter()
+                if not a.forward_only:
+                    o.update_bvh()
+                out = o.raytrace(not a.forward_only, targets=ctg, grads_into=gbuf)
+                rates.append(int(out["effective_steps"].sum()) / (time.perf_counter() - t1) / 1e6)
+            cpu = {"value": round(float(np.median(rates)), 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": f"CPU restatement of the reference algorithm (oracle/), same scene+camera+config at {cw}x{ch}, "
+                             f"{'forward' if a.forward_only else 'update_bvh (refit) + forward+backward'}, median of {len(rates)} reps after 1 warm-up, "
+                             f"OpenMP over 64-pixel blocks, per-thread gradient tables"}
+        res["cpu_baseline"] = cpu
+
+        # ---- per-kernel timing pass (HIP events on the launch stream, untimed region) -> roofline of the dominant kernel
+        roof, kern, acc = None, {}, {}
+        if with_profile:
+            m.set_strands(1)  # one kernel at a time: a kernel's duration is then its exclusive time on the GPU
+            for _ in range(min(a.warmup, 30) if a.profile_steps > 0 else 0):  # the CPU baseline above left the GPU idle: ramp the clocks again
+                one_step()
+            m.enable_timing(rank == 0)
+            for _ in range(a.profile_steps):  # every rank runs these steps (they contain the all-reduce); rank 0 reads the stamps
+                one_step()
+                torch.cuda.synchronize()
+                if rank == 0:
+                    for name, ms in m.last_kernel_ms():
+                        acc.setdefault(name, []).append(ms)
+                    acc.setdefault("update_bvh", []).append(m.last_update_bvh_ms())
+                    acc.setdefault("raytrace_total", []).append(m.last_raytrace_ms())
+            m.enable_timing(False)
+            cc = m.get_counters()
+            # Hc of SURVEY 8d = gaussians whose CUBE the segment overlaps (what the reference's intersection program is invoked for),
+            # measured on the GPU by ONE exact-statistics launch of the same frame (cube boxes, egr_set_exact_stats); the default
+            # tree bounds ellipsoids and evaluates a subset (`evaluated_per_ray`). Every rank does this (same call sequence).
+            m.set_exact_stats(True)
+            m.update_bvh()
+            m.get_metadata().total_num_calls.sub_(1)  # the same jitter / bounce random stream as the last profiled launch
+            with torch.no_grad():
+                m.raytrace()
+            ce = m.get_counters()
+            m.set_exact_stats(False)
+            m.update_bvh()
+            barrier()
+        if rank == 0 and with_profile and a.profile_steps > 0:
+            kern = {k: float(np.median(v)) for k, v in acc.items() if v and v[0] >= 0}
+            rays, cand_eval, comp = cc[0:3], list(cc[3:6]), cc[6:9]
+            cand = [ce[3 + s] * (rays[s] / max(ce[s], 1)) for s in range(3)]  # (grad / no-grad launches trace the same rays; guard anyway)
+            pixels_rank = rays[0]
+            fk = "forward_nograd" if a.forward_only else "forward"
+            fwd_ref = sum(algorithmic_bytes(fk, s, rays[s], cand[s], comp[s], pixels_rank) for s in range(3))
+            fwd_eval = sum(algorithmic_bytes(fk, s, rays[s], cand_eval[s], comp[s], pixels_rank) for s in range(3))
+            cands = {"forward_chain": fwd_ref}
             if not a.forward_only:
-                cands[f"backward_step{s}"] = algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank)
-        if "forward_chain" in kern:  # the fused per-tile chain ran (few tiles per wave slot): one kernel does the three forward steps
-            cands["forward_chain"] = sum(cands.pop(f"forward_step{s}") for s in range(3))
-        if "backward_chain" in kern:
-            cands["backward_chain"] = sum(cands.pop(f"backward_step{s}") for s in range(3))
-        dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
-        achieved = cands[dom] / (kern[dom] * 1e-3) / 1e9
-        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes of this command (profiles/<round>/
-        # pmc_summary.json, collected by tools/profile.sh in separate FETCH_SIZE / WRITE_SIZE passes; units of KiB;
-        # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md). bench.py cannot run the profiler itself.
-        traffic = None
-        try:
-            rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_summary.json")))
-            if rounds and world == 1 and a.emulate_world <= 1 and not a.forward_only:
-                pm = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "pmc_summary.json"))).get(dom)
-                if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-        except Exception:
-            traffic = None
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                "traffic": traffic, "avg_kernel_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": cands[dom],
-                "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
-                "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
-                "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
-                "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
-                "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
+                cands["backward_chain"] = sum(algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank) for s in range(3))
+            dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
+            achieved = cands[dom] / (kern[dom] * 1e-3) / 1e9
+            # HBM traffic of the same kernel: rocprofv3 --pmc passes of THIS command collected in THIS round by tools/profile.sh
+            # (separate FETCH_SIZE / WRITE_SIZE passes; units of KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)
+            # and committed as profiles/<round>/pmc_summary.json. bench.py cannot run the profiler around itself.
+            traffic, traffic_src = None, None
+            try:
+                pj = os.path.join(ROOT, "profiles", ROUND, "pmc_summary.json")
+                if os.path.exists(pj) and world == 1 and a.emulate_world <= 1 and a.config == "C" and variant == "trained" and N == 1_000_000:
+                    pm = json.load(open(pj)).get(dom)
+                    if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                        traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+                        traffic_src = f"profiles/{ROUND}/pmc_summary.json (rocprofv3 --pmc, this round, same command; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
+            except Exception:
+                traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": cands[dom],
+                    "evaluated_frac": round((fwd_eval if dom == "forward_chain" else cands[dom]) / (kern[dom] * 1e-3) / 1e9 / 8000.0, 5),
+                    "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
+                    "Hc_source": "one exact-statistics launch of the same frame on the GPU (cube boxes; reference-defined count)",
+                    "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
+                    "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
+                    "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
+                    "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
+        res["roofline"], res["kernel_ms"] = roof, {k: round(v, 4) for k, v in kern.items()}
+        del rt, pc
+        torch.cuda.empty_cache()
+        return res
 
+    what = "forward only (no_grad, no BVH update between frames: measure_fps.py protocol)" if a.forward_only else \
+        "one training iteration: export + update_bvh + forward + backward + grad import"
+    label = {"trained": "trained-like opacity 0.8: reflection bounces happen, three steps per pixel", "init": "literal dense-init opacity 0.1 (config.py:44): Kc ~ 22 per ray, bounces mostly die"}
+    main_res = run_variant(a.variant, True, not a.no_cpu_baseline)
+    other = None
+    if a.config == "C" and world == 1 and not a.no_second_variant and a.emulate_world <= 1 and not a.forward_only:
+        ov = "init" if a.variant == "trained" else "trained"
+        r2 = run_variant(ov, True, False)
+        other = {"variant": ov, "value": round(r2["value"], 3), "unit": "Mrays/s", "ms_per_step": round(r2["ms_per_step"], 4), "status": r2["status"],
+                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"]}
     if rank == 0:
         line = {
-            "metric": "Mrays/s fwd+bwd @1080p, 1M Gaussians" if not a.forward_only else "Mrays/s fwd-only @1080p",
-            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "Mrays/s fwd+bwd @1080p, 1M Gaussians" if a.config == "C" and not a.forward_only else "Mrays/s fwd-only @1080p",
+            "value": round(main_res["value"], 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic dense-init room+spheres cloud ({a.variant} opacity), N={N}, {W}x{H}, "
-                                   f"{'forward only' if a.forward_only else 'one training iteration: export + update_bvh + forward + backward + grad import'}, "
-                                   f"num_bounces={a.bounces}, jitter on, reference default config",
-                       "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce"},
-            "roofline": roof, "cpu_baseline": cpu, "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
-            "status": int(status), "psnr_vs_optix": None,
+            "config": {"workload": f"BASELINE config {a.config}: synthetic dense-init room+spheres cloud, HEADLINE variant = {a.variant} ({label[a.variant]}; "
+                                   f"the other variant is in `other_variant`), N={N}, {W}x{H}, {what}, num_bounces={a.bounces}, jitter on, reference default config",
+                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients"},
+            "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"], "kernel_ms": main_res["kernel_ms"],
+            "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None,
             "note": "vs_baseline null: the reference publishes no throughput number; PSNR vs OptiX is unmeasurable here (no NVIDIA "
                     "hardware), parity is against the CPU oracle (tests/).",
         }

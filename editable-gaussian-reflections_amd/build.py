@@ -1,6 +1,6 @@
 """In-tree build of the two native artefacts (no cmake, no JIT cache):
 
-  build/libegr_hip.so    hipcc --offload-arch=gfx950   csrc/{trace,epilogue,bvh,api}.hip     the C-ABI product (include/egr_raytracer.h)
+  build/libegr_hip.so    hipcc --offload-arch=gfx950   csrc/{trace,bvh,api}.hip         the C-ABI product (include/egr_raytracer.h)
   build/libraytracer.so  g++ against the installed torch  csrc/torch_binding.cpp      TORCH_LIBRARY(raytracer) shim
 
 hipcc cross-compiles gfx950 without a GPU; both .so files travel to the GPU box with the repo snapshot.
@@ -23,12 +23,14 @@ if os.environ.get("EGR_GPOP"):
     HIP_FLAGS.append("-DEGR_GPOP=" + os.environ["EGR_GPOP"])
 if os.environ.get("EGR_TASK_TIMES"):  # diagnostic: per-task walk / composite time of one step in the stats images (tools/task_times.py)
     HIP_FLAGS.append("-DEGR_TASK_TIMES=" + os.environ["EGR_TASK_TIMES"])
+if os.environ.get("EGR_DEBUG_PIXEL"):
+    HIP_FLAGS.append("-DEGR_DEBUG_PIXEL=" + os.environ["EGR_DEBUG_PIXEL"])
 if os.environ.get("EGR_DEBUG_LIST"):
     HIP_FLAGS.append("-DEGR_DEBUG_LIST=1")
 if os.environ.get("EGR_TRAVERSAL_STATS"):
     HIP_FLAGS.append("-DEGR_TRAVERSAL_STATS=1")
-HIP_SOURCES = ["trace.hip", "epilogue.hip", "bvh.hip", "api.hip", "knn.hip", "step.hip", "denoise.hip"]
-EXTRA_FLAGS = {"epilogue.hip": ["-ffp-contract=off"]}  # see the note at the top of csrc/epilogue.hip
+HIP_SOURCES = ["trace.hip", "bvh.hip", "api.hip", "knn.hip", "step.hip", "denoise.hip"]
+EXTRA_FLAGS = {}
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join(ROOT, "include", "egr_raytracer.h")]  # every object depends on all of them
 
 

@@ -63,22 +63,8 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     egr_context *c = new egr_context();
     c->device = device, c->width = width, c->height = height;
     c->fwd_capacity = ppll_forward_size > 0 ? ppll_forward_size : 1, c->bwd_capacity = ppll_backward_size > 0 ? ppll_backward_size : 1;
-    if (const char *e = getenv("EGR_PACKET_MODE")) c->packet_mode = atoi(e);           // tuning knobs
-    if (const char *e = getenv("EGR_BUCKETED_BACKWARD")) c->bucketed_backward = atoi(e);
-    if (const char *e = getenv("EGR_MORTON_SIZE")) c->morton_size_period = atoi(e);
-    if (const char *e = getenv("EGR_BVH_BUILDER")) c->bvh_builder = atoi(e);
-    if (const char *e = getenv("EGR_COLLAPSE_ABSORB")) c->collapse_absorb = atoi(e);
-    if (const char *e = getenv("EGR_GROUP_WALK")) c->group_walk = atoi(e);
-    if (const char *e = getenv("EGR_BOUNCE_TABLE")) c->bounce_table = atoi(e);
-    if (const char *e = getenv("EGR_WIDE_PRIMARY")) c->wide_primary = atoi(e);
-    if (const char *e = getenv("EGR_SPLIT")) c->split_mode = atoi(e);
-    if (const char *e = getenv("EGR_CHAIN")) c->chain_mode = atoi(e);
-    if (const char *e = getenv("EGR_CHAIN_BELOW")) c->chain_below = atof(e);
-    if (const char *e = getenv("EGR_SPLIT_BELOW")) c->split_below = atof(e);
     if (const char *e = getenv("EGR_DENOISE")) c->denoise_mode = atoi(e);
     if (const char *e = getenv("EGR_STRANDS")) c->strands = std::max(1, std::min(EGR_MAX_STRANDS, atoi(e)));
-    if (const char *e = getenv("EGR_PACKET_COS_MIN")) c->packet_cos_min = (float)atof(e);
-    if (const char *e = getenv("EGR_PACKET_ORIGIN_MAX")) c->packet_origin_max = (float)atof(e);
     int rc = guarded(c, [&] {
         egr_trace_alloc(c);
         EGR_HIP(hipEventCreate(&c->ev_rt0)), EGR_HIP(hipEventCreate(&c->ev_rt1));
@@ -116,10 +102,7 @@ int egr_set_gaussians(egr_context *c, const egr_gaussians *g) {
     if (!c || !g) return 1;
     c->g = *g;
     c->have_gaussians = true;
-    return guarded(c, [&] {
-        egr_bvh_reserve(c, g->count);
-        egr_trace_reserve_buckets(c, g->count);
-    });
+    return guarded(c, [&] { egr_bvh_reserve(c, g->count); });
 }
 
 int egr_set_partition(egr_context *c, int rank, int world) {
@@ -129,6 +112,12 @@ int egr_set_partition(egr_context *c, int rank, int world) {
         EGR_HIP(hipDeviceSynchronize());
         egr_build_task_order(c);
     });
+}
+
+int egr_set_exact_stats(egr_context *c, int enable) {
+    if (!c) return 1;
+    c->exact_stats = enable != 0; // the boxes change at the next egr_update_bvh / egr_rebuild_bvh; egr_raytrace checks that they did
+    return 0;
 }
 
 int egr_set_strands(egr_context *c, int strands) {
@@ -166,6 +155,10 @@ int egr_update_bvh(egr_context *c, void *stream) {
 
 int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
     if (!c || require_ready(c, true)) return 1;
+    if (c->exact_stats != c->boxes_are_cubes) {
+        c->last_error = "libegr_hip: egr_set_exact_stats changed since the tree was last refitted; call egr_update_bvh or egr_rebuild_bvh first";
+        return 1;
+    }
     return guarded(c, [&] {
         hipStream_t s = (hipStream_t)stream;
         c->stamps_used = 0;
@@ -186,6 +179,8 @@ int egr_denoise(egr_context *c, void *stream) {
 int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
     if (!c || !out) return 1;
     return guarded(c, [&] {
+        // the control block only crosses PCIe when somebody asks for it (nothing does inside a training iteration)
+        EGR_HIP(hipMemcpyAsync(c->control_host, c->control, CW_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
         EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
         const uint32_t *w = c->control_host;
         auto u64 = [&](int i) { return (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32); };

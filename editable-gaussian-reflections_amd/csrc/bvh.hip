@@ -40,7 +40,7 @@ inline int nblk(uint64_t n, int bs = BS) { return (int)((n + bs - 1) / bs); }
 // in space then read neighbouring 48-B records (same / adjacent cache lines) instead of lines scattered over the
 // whole array - the scene's own order is arbitrary (the reference never sorts its clouds).
 __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, egr_config cfg, const uint32_t *__restrict__ pos_of_gid,
-                                                  float4 *__restrict__ inst_w, float4 *__restrict__ inst_m, float *__restrict__ aabb) {
+                                                  float4 *__restrict__ inst_w, float4 *__restrict__ inst_m, float *__restrict__ aabb, int cube) {
     uint32_t i = blockIdx.x * BS + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = pos_of_gid ? pos_of_gid[i] : i;
@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
         finite = finite && isfinite(W0 + W1 + W2 + Wr[a].w);
         // Box of the ELLIPSOID M * (unit sphere): half-extent = |row of M|_2 (not the cube's |row|_1). Accepted hits have
         // their response point inside it (see the three-segment walk in trace.hip); padded against fp32 rounding.
-        float ext = sqrtf(M0 * M0 + M1 * M1 + M2 * M2);
+        // Exact-statistics mode (egr_set_exact_stats): the box of the instance CUBE M * [-1,1]^3, what OptiX's TLAS bounds.
+        float ext = cube ? fabsf(M0) + fabsf(M1) + fabsf(M2) : sqrtf(M0 * M0 + M1 * M1 + M2 * M2);
         ext = ext * 1.0001f + 4e-7f * (fabsf(m[a]) + ext);
         lo[a] = m[a] - ext;
         hi[a] = m[a] + ext;
@@ -138,40 +139,19 @@ __device__ __forceinline__ uint64_t spread21(uint32_t v) { // 21 bits -> every t
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
-// Sort key of a gaussian: Morton code of its mean, optionally EXTENDED with the size of its box (Vinkler, Bittner, Havran 2017:
-// "Extended Morton codes for high performance bounding volume hierarchy construction"): the key interleaves quantised
-// x, y, z and size bits following `pattern` (period `period`, dimension 3 = size). A gaussian much larger than the cell
-// it sits in is then split off into its own subtree at the level where the cell size reaches its own size, instead of
-// inflating the boxes of all the small gaussians that share its Morton cell.
-struct MortonPattern {
-    uint8_t dim[8];
-    uint32_t period;
-};
-__global__ void __launch_bounds__(BS) k_morton(uint32_t n, const float *__restrict__ mean, const float *__restrict__ aabb, BvhFrame fr, MortonPattern pat,
-                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// Sort key of a gaussian: 63-bit Morton code of its mean in the build frame (21 bits per axis).
+__global__ void __launch_bounds__(BS) k_morton(uint32_t n, const float *__restrict__ mean, BvhFrame fr, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * BS + threadIdx.x;
     if (i >= n) return;
     const float fo[3] = {fr.ox, fr.oy, fr.oz}, fs[3] = {fr.sx, fr.sy, fr.sz};
-    uint32_t q[4]; // 21-bit fixed point in [0,1): x, y, z, size
-    float size = 0.0f;
+    uint32_t q[3]; // 21-bit fixed point in [0,1)
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         float v = mean[3 * i + a];
         float u = isfinite(v) ? (v - fo[a]) * fs[a] * (1.0f / 65536.0f) : 0.0f; // [0,1) inside the frame
         q[a] = (uint32_t)fminf(fmaxf(u * 2097152.0f, 0.0f), 2097151.0f);
-        const float ext = (aabb[6 * i + 3 + a] - aabb[6 * i + a]) * fs[a] * (1.0f / 65536.0f); // box extent / frame extent
-        size = fmaxf(size, (ext >= 0.0f && ext <= 1.0f) ? ext : 0.0f);                          // unusable (empty) boxes: 0
     }
-    q[3] = (uint32_t)fminf(size * 2097152.0f, 2097151.0f);
-    uint64_t key = 0;
-    int used[4] = {0, 0, 0, 0};
-    for (int b = 0; b < 63; b++) {
-        const int d = pat.dim[b % pat.period];
-        const uint32_t bit = used[d] < 21 ? (q[d] >> (20 - used[d])) & 1u : 0u;
-        used[d]++;
-        key = (key << 1) | bit;
-    }
-    keys[i] = key;
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
     vals[i] = i;
 }
 __global__ void __launch_bounds__(BS) k_inverse_perm(uint32_t n, const uint32_t *__restrict__ gid_of_pos, uint32_t *__restrict__ pos_of_gid) {
@@ -230,7 +210,7 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
                                                        const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                                        const uint32_t *__restrict__ first, const uint32_t *__restrict__ last,
                                                        uint32_t *__restrict__ wide_of, uint32_t *__restrict__ counters, // [0] = #wide nodes, [1] = next frontier size
-                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes, int absorb) {
+                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes) {
     uint32_t t = blockIdx.x * BS + threadIdx.x;
     if (t >= count) return;
     const int b = (int)frontier_in[t];
@@ -249,7 +229,7 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
         for (int k = 0; k < nchild; k++) {
             uint32_t l = leaves_of(child[k]);
             if (l > best_leaves) best_leaves = l, best = k;
-            if (absorb && l > fit_leaves && l - 1u <= free_slots) fit_leaves = l, fit = k;
+            if (l > fit_leaves && l - 1u <= free_slots) fit_leaves = l, fit = k;
         }
         if (fit >= 0) best = fit;
         if (best < 0) break; // only leaves left
@@ -274,25 +254,6 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
         }
         wnodes[(size_t)w * EGR_WIDTH + k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, link); // empty box until refit
     }
-}
-
-// Alternative topology (EGR_BVH_BUILDER=1): a COMPLETE 8-ary tree over the Morton order - bottom nodes hold 8 consecutive sorted
-// gaussians, every upper node 8 consecutive nodes of the level below. All nodes but the last of a level are full (N/7 nodes
-// instead of ~N/5), at the price of groups that ignore the Morton prefix boundaries the Karras splits follow.
-// Level d (root = 0) has cnt[d] nodes starting at off[d]; the deepest level's slots are leaves.
-__global__ void __launch_bounds__(BS) k_implicit_level(uint32_t n, uint32_t off, uint32_t cnt, uint32_t child_off, uint32_t child_cnt, int bottom,
-                                                       uint4 *__restrict__ wnodes) {
-    const uint32_t t = blockIdx.x * BS + threadIdx.x; // one thread per child slot
-    const uint32_t i = t / EGR_WIDTH, k = t % EGR_WIDTH;
-    if (i >= cnt) return;
-    const uint32_t c = i * EGR_WIDTH + k;
-    uint32_t link = EGR_EMPTY_SLOT;
-    if (bottom) {
-        if (c < n) link = EGR_LEAF_FLAG | c;
-    } else if (c < child_cnt) {
-        link = child_off + c;
-    }
-    wnodes[(size_t)(off + i) * EGR_WIDTH + k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, link); // empty box until refit
 }
 
 // ---- 16-bit box quantisation in the build frame. u = (x - origin) * scale + 2 (cells); lo rounds down one extra
@@ -411,11 +372,12 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     c->max_depth = 0;
     c->level_start.assign(1, 0);
     c->frame = BvhFrame{0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
+    c->boxes_are_cubes = c->exact_stats;
     if (n == 0) {
         c->bvh_valid = true;
         return;
     }
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb); // boxes for the frame
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0); // boxes for the frame
     uint32_t *bounds = c->scratch_u32, *counters = c->scratch_u32 + 16;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, bounds);
     hipLaunchKernelGGL(k_bounds, dim3(nblk(n)), dim3(BS), 0, s, n, c->aabb, bounds);
@@ -434,20 +396,11 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->frame.ox = lo[0], c->frame.oy = lo[1], c->frame.oz = lo[2];
         c->frame.sx = 65530.0f / (hi[0] - lo[0]), c->frame.sy = 65530.0f / (hi[1] - lo[1]), c->frame.sz = 65530.0f / (hi[2] - lo[2]);
     }
-    MortonPattern pat{{0, 1, 2, 0, 1, 2, 0, 0}, 3u};
-    if (c->morton_size_period > 0) { // x y z (repeated `morton_size_period` times) then one size bit
-        pat.period = 0;
-        const int reps = std::min(c->morton_size_period, 2);
-        for (int r = 0; r < reps; r++) pat.dim[pat.period++] = 0, pat.dim[pat.period++] = 1, pat.dim[pat.period++] = 2;
-        pat.dim[pat.period++] = 3;
-    } else if (c->morton_size_period < 0) { // size bit first: s x y z
-        pat.dim[0] = 3, pat.dim[1] = 0, pat.dim[2] = 1, pat.dim[3] = 2, pat.period = 4;
-    }
-    hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(BS), 0, s, n, c->g.mean, c->aabb, c->frame, pat, c->keys_in, c->vals_in);
+    hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(BS), 0, s, n, c->g.mean, c->frame, c->keys_in, c->vals_in);
     size_t bytes = c->sort_tmp_bytes;
     EGR_HIP(rocprim::radix_sort_pairs(c->sort_tmp, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)n, 0, 63, s));
     hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(n)), dim3(BS), 0, s, n, c->vals_out, c->pos_of_gid);
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb); // records in leaf order
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0); // records in leaf order
     if (n == 1) { // a single leaf under a one-child root
         uint4 root[EGR_WIDTH];
         for (int k = 0; k < EGR_WIDTH; k++) root[k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, k == 0 ? (EGR_LEAF_FLAG | 0u) : EGR_EMPTY_SLOT);
@@ -455,21 +408,6 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         EGR_HIP(hipStreamSynchronize(s));
         c->num_wide = 1;
         c->level_start = {0, 1};
-    } else if (c->bvh_builder == 1) {
-        std::vector<uint32_t> cnt; // nodes per level, bottom first
-        for (uint32_t m = (n + EGR_WIDTH - 1) / EGR_WIDTH;; m = (m + EGR_WIDTH - 1) / EGR_WIDTH) {
-            cnt.push_back(m);
-            if (m == 1) break;
-        }
-        std::reverse(cnt.begin(), cnt.end()); // root first
-        c->level_start.assign(1, 0);
-        for (uint32_t m : cnt) c->level_start.push_back(c->level_start.back() + m);
-        for (size_t d = 0; d < cnt.size(); d++) {
-            const bool bottom = d + 1 == cnt.size();
-            hipLaunchKernelGGL(k_implicit_level, dim3(nblk((uint64_t)cnt[d] * EGR_WIDTH)), dim3(BS), 0, s, n, c->level_start[d], cnt[d],
-                               bottom ? 0u : c->level_start[d + 1], bottom ? 0u : cnt[d + 1], bottom ? 1 : 0, c->wnodes);
-        }
-        c->num_wide = c->level_start.back();
     } else {
         hipLaunchKernelGGL(k_karras, dim3(nblk(n - 1)), dim3(BS), 0, s, (int)n, c->keys_out, c->k_left, c->k_right, c->k_parent, c->k_first,
                            c->k_last);
@@ -484,7 +422,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->level_start = {0, 1};
         while (count > 0) {
             hipLaunchKernelGGL(k_collapse_level, dim3(nblk(count)), dim3(BS), 0, s, (int)n, count, fr0, c->k_left, c->k_right, c->k_first, c->k_last,
-                               c->wide_of, counters, fr1, c->wnodes, c->collapse_absorb);
+                               c->wide_of, counters, fr1, c->wnodes);
             uint32_t hc[2];
             EGR_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
             EGR_HIP(hipStreamSynchronize(s));
@@ -506,8 +444,9 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
 void egr_bvh_refit(egr_context *c, hipStream_t s) {
     const uint32_t n = c->g.count;
     if (!c->bvh_valid || n != c->n_built) throw EgrCheck{hipErrorInvalidValue, "update_bvh: tree was built for a different gaussian count; call rebuild_bvh"};
+    c->boxes_are_cubes = c->exact_stats;
     if (n == 0) return;
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb);
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0);
     refit_boxes(c, s);
 }
 

@@ -16,9 +16,9 @@
 #define EGR_LEAF_FLAG 0x80000000u  // child slot link: leaf -> EGR_LEAF_FLAG | record index, internal -> child node index
 #define EGR_EMPTY_SLOT 0xFFFFFFFFu // unused child slot (checked before the leaf flag)
 #define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
-#define EGR_BUCKET_SHIFT 9         // gradient buckets of 512 Morton-consecutive gaussians (bounce-step backward)
 #define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
 #define EGR_MAX_STRANDS 4
+#define EGR_QUEUE_WORDS 16u          // task queue heads per strand: 2 kernels (forward chain, backward chain) x 8 XCD heads
 #define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
 #define EGR_EXT_BLOCK 16384u // entries of one candidate-list extension block
 #define EGR_EXT_NONE 0xFFFFFFFFu
@@ -87,31 +87,20 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t num_slots;    // resident waves
     float4 *hit_arena;     // blocks of (1 + EGR_HIT_BLOCK_ROWS) rows x 64 lanes
     uint32_t hit_blocks_cap;
-    uint32_t *task_last_block; // [NSTEPS][num_task_slots]  last arena block of the task (or ~0u)
+    uint32_t *task_last_block; // [NSTEPS][num_tasks]  last arena block of the task's step (or ~0u)
     float *state;          // internal per-ray state, SoA by task-linear index (see trace.hip)
     uint32_t state_stride; // = padded number of task-linear rays
     uint32_t *control;     // device counters (see ControlWord)
-    int packet_mode;       // 0 per-lane walk only, 1 packet walk for primary rays, 2 adaptive (coherence test per tile)
-    float packet_cos_min, packet_origin_max;
-    float4 *gb_data;       // [buckets][gb_cap][4] 64-B gradient records of the bounce-step backward
-    uint32_t *gb_count;    // [buckets]
-    uint32_t gb_cap;
     uint32_t task_begin, task_count; // this strand's slice of the rank's task order (see egr_trace_launch)
-    uint32_t *queues;      // [strands][6 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
+    uint32_t *queues;      // [strands][2 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
-    int wide_primary;      // 1: the primary step's table flush adds rows as 16-lane records too (EGR_WIDE_PRIMARY)
-    int bounce_table;      // 0: bounce-step hits skip the LDS table and go out as records (experiment, EGR_BOUNCE_TABLE)
-    int log_mode;          // bounce-step records go to one launch-wide log instead of per-gaussian-block buckets
-    uint32_t log_cap;      // log mode: records per resident wave slot
-    uint32_t log_slot0;    // log mode: first wave slot of this strand
-    int group_walk;        // 1: incoherent tiles walk with 8 lanes per ray (see k_forward), 0: one lane per ray
-    uint32_t split_mask;   // bit s: forward step s runs as quarter tiles (16 rays per wave), its arena chains are per quarter
+    int cube_mode;         // exact-statistics launch (egr_set_exact_stats): the tree bounds instance CUBES, every overlap is counted
 };
 
 enum ControlWord : int {
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
-    CW_BUCKET_RECORDS = 7, // records summed by k_bucket_reduce in this launch
+    CW_BUCKET_RECORDS = 7, // gradient records the bounce-step backward added to the gradient rows in this launch
     CW_EXT_BUMP = 6,       // candidate-list extension blocks handed out in this launch
     CW_RAYS = 10,       // per-step 64-bit counters (two words each): rays[3], candidates[3], composited[3]
     CW_CAND = 16,
@@ -168,24 +157,13 @@ struct egr_context {
     float *cand_keys = nullptr;
     float2 *cand_vals = nullptr;
     uint32_t *cand_queue = nullptr, *stack_spill = nullptr;
-    float4 *gb_data = nullptr;
-    uint32_t *gb_count = nullptr, gb_cap = 0, gb_buckets_alloc = 0;
-    int bounce_table = 0;      // 1: bounce-step hits are pre-summed per tile in the LDS table before they leave the wave (EGR_BOUNCE_TABLE)
-    int wide_primary = 1;      // 1: the primary step's table flush adds rows as two 16-lane records (EGR_WIDE_PRIMARY)
-    int bucketed_backward = 3; // bounce-step backward: 3 records added to the gradient rows by 16 lanes each, in the kernel (default); 2 per-wave record logs + k_log_apply; 1 per-block buckets + counting-sort reduce; 0 scalar atomics per hit (EGR_BUCKETED_BACKWARD)
-    int group_walk = 1;
-    int chain_mode = 1;       // fused per-tile chains (k_forward_chain, k_backward_chain): 1 always (default), 0 never (step-by-step kernels), -1 only with few tiles per wave slot (EGR_CHAIN)
-    double chain_below = 4.0; // auto: chain when a strand has fewer tiles than this many per wave slot (EGR_CHAIN_BELOW)
-    int split_mode = 0;       // quarter-tile bounce steps: 0 never (default: measured neutral), 1 always, -1 auto (few tiles per wave slot) (EGR_SPLIT)
-    double split_below = 2.0; // auto: split when a strand has fewer tiles than this many per wave slot (EGR_SPLIT_BELOW)
-    int bvh_builder = 0;          // 0: Karras binary LBVH collapsed to 8-wide, 1: complete 8-ary tree over the Morton order
-    int collapse_absorb = 1;      // wide-BVH collapse: dissolve small subtrees into their parent node (see k_collapse_level)
+    bool exact_stats = false;     // egr_set_exact_stats: cube boxes + reference-defined candidate count (takes effect at the next update / rebuild)
+    bool boxes_are_cubes = false; // what the current tree was refitted with
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final
     float *ext_keys = nullptr;    // candidate-list extension blocks (see DeviceView)
     float2 *ext_vals = nullptr;
     uint32_t ext_blocks_cap = 0;
     float *denoise_tmp = nullptr; // two W*H*3 ping-pong images, allocated on first use
-    int morton_size_period = 0; // 0: plain Morton order; k > 0: one size bit after every k xyz triples; < 0: size bit first (s x y z)
     // strands: the rank's tiles are cut into `strands` slices whose kernel sequences run on separate HIP streams, so one
     // slice's persistent-wave tail (few long tiles left) is filled by the other slice's next kernel
     int strands = 3;        // allocated (scratch, streams); 3 strands + the caller's stream = the 4 HW queues of the runtime
@@ -209,8 +187,6 @@ struct egr_context {
     bool have_rt = false, have_ub = false;
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
-    int packet_mode = 1;
-    float packet_cos_min = 0.98f, packet_origin_max = 0.25f;
     std::string last_error;
 };
 
@@ -226,7 +202,6 @@ void egr_trace_free(egr_context *c);
 void egr_trace_launch(egr_context *c, bool grads, hipStream_t s);
 uint32_t egr_num_tasks_for_rank(const egr_context *c);
 void egr_build_task_order(egr_context *c);
-void egr_trace_reserve_buckets(egr_context *c, uint32_t n);
 DeviceView egr_make_view(const egr_context *c);
 // timing helpers (api.hip)
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s);

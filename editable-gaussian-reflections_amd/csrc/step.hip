@@ -22,7 +22,8 @@ namespace {
 struct StepArgs {
     egr_param_group g[EGR_MAX_PARAM_GROUPS];
     float step_size[EGR_MAX_PARAM_GROUPS]; // lr / (1 - beta1^t)
-    float w1, beta2, w2, bc2_sqrt, eps;    // w1 = 1 - beta1, w2 = 1 - beta2
+    float bc2_sqrt[EGR_MAX_PARAM_GROUPS];  // sqrt(1 - beta2^t); t is per group (torch keeps one step count per parameter tensor)
+    float w1, beta2, w2, eps;              // w1 = 1 - beta1, w2 = 1 - beta2
     uint32_t n;
 };
 
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(256) k_fused_step(StepArgs a) {
             float m = G.exp_avg[i], v = G.exp_avg_sq[i];
             m = m + a.w1 * (g - m);         // lerp_(grad, 1 - beta1)
             v = v * a.beta2 + a.w2 * g * g; // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-            const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+            const float denom = sqrtf(v) / a.bc2_sqrt[blockIdx.y] + a.eps;
             p = p - a.step_size[blockIdx.y] * (m / denom); // addcdiv_(exp_avg, denom, value = -step_size)
             G.exp_avg[i] = m, G.exp_avg_sq[i] = v;
         }
@@ -71,11 +72,12 @@ extern "C" int egr_fused_adam_step(int device, const egr_param_group *groups, in
             g_step_error = "libegr_hip: egr_fused_adam_step: group without parameter / width, or with only one Adam moment";
             return 1;
         }
-        a.step_size[k] = (float)((double)groups[k].lr / (1.0 - std::pow(beta1, (double)step)));
+        const double t = (double)(groups[k].step ? groups[k].step : step); // a group whose optimizer state was re-created counts from its own 1
+        a.step_size[k] = (float)((double)groups[k].lr / (1.0 - std::pow(beta1, t)));
+        a.bc2_sqrt[k] = (float)std::sqrt(1.0 - std::pow(beta2, t));
         wmax = std::max(wmax, groups[k].width);
     }
     a.w1 = (float)(1.0 - beta1), a.beta2 = (float)beta2, a.w2 = (float)(1.0 - beta2);
-    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, (double)step));
     a.eps = (float)eps;
     a.n = n;
     hipError_t e = hipSetDevice(device);

@@ -218,22 +218,40 @@ struct GaussianDataHolder : torch::CustomClassHolder {
         roughness.mutable_grad() = dL_droughness, opacity.mutable_grad() = dL_dopacity, scale.mutable_grad() = dL_dscale;
         mean.mutable_grad() = dL_dmean, rotation.mutable_grad() = dL_drotation;
     }
-    void resize(int64_t n) { // gaussians.h:64-86; unlike upstream, grown gradient memory is zeroed
+    // Multi-GPU (not in the reference): with `use_delta` the kernels accumulate THIS launch's gradients and weights into a zeroed
+    // [22N] buffer of their own (grad_delta) instead of the persistent one, so the caller can all-reduce exactly one launch's
+    // contribution and then fold it in (renderer.py: all_reduce_grads) - summing the persistent buffer would multiply whatever it
+    // already holds (total_weight across a pruning interval, accumulated gradients) by the world size on every iteration.
+    Tensor grad_delta = torch::empty({0}, F32());
+    bool use_delta = false;
+    void set_use_delta(bool on) {
+        use_delta = on;
+        grad_delta = on ? torch::zeros({22 * count}, F32()) : torch::empty({0}, F32());
+    }
+    void resize(int64_t n) { // gaussians.h:64-86: resize_ keeps the first min(old, n) rows of every tensor; grown gradient memory is zeroed here
         torch::NoGradGuard no_grad;
+        const int64_t keep = std::min(count, n);
+        Tensor old_rows[9] = {dL_drgb.narrow(0, 0, keep).clone(), dL_dnormal.narrow(0, 0, keep).clone(), dL_df0.narrow(0, 0, keep).clone(),
+                              dL_droughness.narrow(0, 0, keep).clone(), dL_dopacity.narrow(0, 0, keep).clone(), dL_dscale.narrow(0, 0, keep).clone(),
+                              dL_dmean.narrow(0, 0, keep).clone(), dL_drotation.narrow(0, 0, keep).clone(), total_weight.narrow(0, 0, keep).clone()};
         count = n;
         rgb.resize_({n, 3}), normal.resize_({n, 3}), f0.resize_({n, 3}), roughness.resize_({n, 1}), opacity.resize_({n, 1});
         scale.resize_({n, 3}), mean.resize_({n, 3}), rotation.resize_({n, 4});
         grad_flat = torch::zeros({22 * n}, F32());
         point_grads();
+        Tensor *win[9] = {&dL_drgb, &dL_dnormal, &dL_df0, &dL_droughness, &dL_dopacity, &dL_dscale, &dL_dmean, &dL_drotation, &total_weight};
+        for (int k = 0; k < 9 && keep > 0; k++) win[k]->narrow(0, 0, keep).copy_(old_rows[k]);
+        if (use_delta) grad_delta = torch::zeros({22 * n}, F32());
     }
     egr_gaussians reify() {
         egr_gaussians g;
         g.count = (uint32_t)count;
         g.rgb = ptr<float>(rgb), g.normal = ptr<float>(normal), g.f0 = ptr<float>(f0), g.roughness = ptr<float>(roughness);
         g.opacity = ptr<float>(opacity), g.scale = ptr<float>(scale), g.mean = ptr<float>(mean), g.rotation = ptr<float>(rotation);
-        g.dL_drgb = ptr<float>(dL_drgb), g.dL_dnormal = ptr<float>(dL_dnormal), g.dL_df0 = ptr<float>(dL_df0);
-        g.dL_droughness = ptr<float>(dL_droughness), g.dL_dopacity = ptr<float>(dL_dopacity), g.dL_dscale = ptr<float>(dL_dscale);
-        g.dL_dmean = ptr<float>(dL_dmean), g.dL_drotation = ptr<float>(dL_drotation), g.total_weight = ptr<float>(total_weight);
+        float *base = use_delta ? ptr<float>(grad_delta) : ptr<float>(grad_flat); // same tensor-major layout as point_grads()
+        const size_t n = (size_t)count;
+        g.dL_drgb = base, g.dL_dnormal = base + 3 * n, g.dL_df0 = base + 6 * n, g.dL_droughness = base + 9 * n, g.dL_dopacity = base + 10 * n;
+        g.dL_dscale = base + 11 * n, g.dL_dmean = base + 14 * n, g.dL_drotation = base + 17 * n, g.total_weight = base + 21 * n;
         return g;
     }
     static void bind(torch::Library &m) {
@@ -255,7 +273,8 @@ struct GaussianDataHolder : torch::CustomClassHolder {
             .def_readonly("dL_dmean", &GaussianDataHolder::dL_dmean)
             .def_readonly("dL_drotation", &GaussianDataHolder::dL_drotation)
             .def_readonly("total_weight", &GaussianDataHolder::total_weight)
-            .def_readonly("grad_flat", &GaussianDataHolder::grad_flat); // addition: [22N] view of all of the above
+            .def_readonly("grad_flat", &GaussianDataHolder::grad_flat)    // addition: [22N] view of all of the above
+            .def_readonly("grad_delta", &GaussianDataHolder::grad_delta); // addition: per-launch accumulation target (empty unless use_grad_delta)
     }
 };
 
@@ -374,6 +393,14 @@ struct Raytracer : torch::CustomClassHolder {
     }
     // ---- additions (not in the reference) ----
     void set_partition(int64_t rank, int64_t world) { check(egr_set_partition(ctx, (int)rank, (int)world), "set_partition"); }
+    void use_grad_delta(bool on) { // see GaussianDataHolder::grad_delta
+        gaussian_data->set_use_delta(on);
+        egr_gaussians g = gaussian_data->reify();
+        check(egr_set_gaussians(ctx, &g), "use_grad_delta");
+    }
+    // exact statistics: num_traversed_per_pixel / the candidate counters become the reference's intersection-program invocation
+    // count (cube boxes, slower). Takes effect with the next update_bvh() / rebuild_bvh(); raytrace() refuses to run in between.
+    void set_exact_stats(bool on) { check(egr_set_exact_stats(ctx, on ? 1 : 0), "set_exact_stats"); }
     void set_strands(int64_t n) { TORCH_CHECK(egr_set_strands(ctx, (int)n) == 0, "set_strands: 1..EGR_STRANDS (value at creation) expected"); }
     std::vector<int64_t> get_counters() { // synchronises
         egr_counters c{};
@@ -456,6 +483,8 @@ struct Raytracer : torch::CustomClassHolder {
                  })
             // additions for multi-GPU tile partitioning, measurement and tests
             .def("set_partition", &Raytracer::set_partition)
+            .def("use_grad_delta", &Raytracer::use_grad_delta)
+            .def("set_exact_stats", &Raytracer::set_exact_stats)
             .def("set_strands", &Raytracer::set_strands)
             .def("get_counters", &Raytracer::get_counters)
             .def("reset_lifetime_counters", &Raytracer::reset_lifetime_counters)
@@ -485,7 +514,7 @@ static torch::Tensor dist_hip2(const torch::Tensor &points) {
 static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch::Tensor> grads, std::vector<torch::Tensor> rt_params,
                             std::vector<torch::Tensor> rt_grads, std::vector<torch::Tensor> exp_avg, std::vector<torch::Tensor> exp_avg_sq,
                             std::vector<double> lrs, std::vector<double> clamp_min, std::vector<double> clamp_max, std::vector<double> log_decay,
-                            int64_t step, double beta1, double beta2, double eps) {
+                            int64_t step, double beta1, double beta2, double eps, std::vector<int64_t> group_steps) {
     const size_t G = params.size();
     TORCH_CHECK(G >= 1 && G <= EGR_MAX_PARAM_GROUPS, "fused_adam_step: 1..8 parameter groups");
     TORCH_CHECK(grads.size() == G && rt_params.size() == G && rt_grads.size() == G && exp_avg.size() == G && exp_avg_sq.size() == G && lrs.size() == G &&
@@ -508,6 +537,7 @@ static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch
         g[k].exp_avg = ptr(exp_avg[k], params[k], "exp_avg"), g[k].exp_avg_sq = ptr(exp_avg_sq[k], params[k], "exp_avg_sq");
         g[k].width = n ? (uint32_t)(params[k].numel() / n) : 1u;
         g[k].lr = (float)lrs[k], g[k].clamp_min = (float)clamp_min[k], g[k].clamp_max = (float)clamp_max[k], g[k].log_decay = (float)log_decay[k];
+        g[k].step = group_steps.size() == G ? (uint32_t)group_steps[k] : 0u;
     }
     const int rc = egr_fused_adam_step(params[0].get_device(), g, (int)G, (uint32_t)n, (uint32_t)step, beta1, beta2, eps, current_stream());
     TORCH_CHECK(rc == 0, egr_fused_step_last_error());
@@ -516,7 +546,7 @@ static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch
 TORCH_LIBRARY(simple_knn, m) { m.def("distCUDA2(Tensor points) -> Tensor", &dist_hip2); }
 TORCH_LIBRARY(egr, m) {
     m.def("fused_adam_step(Tensor[] params, Tensor[] grads, Tensor[] rt_params, Tensor[] rt_grads, Tensor[] exp_avg, Tensor[] exp_avg_sq, float[] lrs, "
-          "float[] clamp_min, float[] clamp_max, float[] log_decay, int step, float beta1, float beta2, float eps) -> ()",
+          "float[] clamp_min, float[] clamp_max, float[] log_decay, int step, float beta1, float beta2, float eps, int[] group_steps) -> ()",
           &fused_adam_step);
 }
 

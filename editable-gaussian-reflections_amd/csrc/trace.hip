@@ -6,8 +6,7 @@
 //     (ragged per-ray work: 1..1000s of candidates), one workgroup = one wave so waves never wait on each other;
 //   * a tile runs through ALL its steps in one go (k_forward_chain: trace, step epilogue, trace, ...; k_backward_chain), so
 //     a launch pays the tail of its heaviest tile once per chain, not once per step. The per-step source lives in
-//     forward_task.inc / backward_task.inc / egr_epilogue.hpp and is also built as one kernel per step (k_forward,
-//     k_step_epilogue, k_backward; EGR_CHAIN=0). Per-ray state lives in a task-linear SoA buffer (fully coalesced);
+//     forward_task.inc / backward_task.inc / egr_epilogue.hpp. Per-ray state lives in a task-linear SoA buffer (fully coalesced);
 //   * the 8-wide BVH (128-B line-sized nodes, 16-bit child boxes) is walked as ONE packet by coherent tiles (primary rays:
 //     scalar loads, every lane tests its own ray) and by GROUPS OF EIGHT LANES PER RAY by incoherent tiles (lane m tests
 //     child m; ballot compaction onto a per-ray LDS stack and leaf queue; groups take rays from a shared per-tile list);
@@ -23,7 +22,7 @@
 //     contributions per gaussian in an LDS hash table (DPP neighbour pre-reduction first); whatever leaves the wave - a
 //     bounce hit, a flushed table slot - is added to its gaussian's position-ordered gradient row by SIXTEEN LANES PER
 //     RECORD (one 64-B non-returning atomic request instead of 15 scattered ones; wide_add_wave); k_grad_gather scatters
-//     the rows to the reference's gradient tensors. (EGR_BUCKETED_BACKWARD = 2 / 1 / 0 keep the earlier record paths.)
+//     the rows to the reference's gradient tensors.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -188,6 +187,22 @@ EGR_DI bool hits_unit_cube(f3 lo, f3 ld, float tmin, float tmax) {
     return ok && t0 <= t1;
 }
 
+// The same test with IEEE divisions, operation for operation what the CPU oracle evaluates (exact-statistics build only).
+EGR_DI bool hits_unit_cube_exact(f3 lo, f3 ld, float tmin, float tmax) {
+    float t0 = tmin, t1 = tmax;
+    bool ok = true;
+#define EGR_AXIS(c)                                                            \
+    if (ld.c != 0.0f) {                                                        \
+        float a = (-1.0f - lo.c) / ld.c, b = (1.0f - lo.c) / ld.c;             \
+        t0 = fmaxf(t0, fminf(a, b));                                           \
+        t1 = fminf(t1, fmaxf(a, b));                                           \
+    } else if (lo.c < -1.0f || lo.c > 1.0f)                                    \
+        ok = false;
+    EGR_AXIS(x) EGR_AXIS(y) EGR_AXIS(z)
+#undef EGR_AXIS
+    return ok && t0 <= t1;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // per-launch prologue: Raytracer::raytrace host part (raytracer.cpp:82-86), on the device, no host sync
 // ---------------------------------------------------------------------------------------------------------
@@ -196,7 +211,7 @@ __global__ void k_prologue(DeviceView v, int grads) {
     if (t < CW_RESET_END) v.control[t] = 0;
     if (t >= CW_DBG && t < CW_COUNT) v.control[t] = 0;
     if (t < 16) v.control[CW_DBG2 + t] = 0;
-    for (uint32_t q = t; q < 48u * v.num_strands; q += blockDim.x) v.queues[q] = 0;
+    for (uint32_t q = t; q < EGR_QUEUE_WORDS * v.num_strands; q += blockDim.x) v.queues[q] = 0;
     if (t < 12) v.control[CW_DBG3 + t] = ((t & 3) < 2) ? 0xFFFFFFFFu : 0u;
     if (t == 0) {
         *v.meta.grads_enabled = grads ? 1 : 0;   // metadata.h:29
@@ -214,8 +229,11 @@ __global__ void k_epilogue(DeviceView v, int grads) {
     }
 }
 // per-launch live record: activated appearance + (opacity, sigma). Reads the CURRENT parameter tensors, like
-// the reference's read_* helpers do inside the launch (utils/helpers.cu:10-33), while inst_w/inst_m stay snapshots.
-__global__ void __launch_bounds__(256) k_live(DeviceView v) {
+// the reference's read_* helpers do inside the launch (utils/helpers.cu:10-33), while the transforms in inst_w / inst_m stay
+// snapshots of the last update_bvh / rebuild_bvh. Grad launches also refresh the two live quantities of the backward record:
+// exp(scale) and the raw quaternion, which the reference's backward reads from the parameter tensors (backward_pass.cu:68-70)
+// next to OptiX's snapshot transforms (:75-78).
+__global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= v.n) return;
     const egr_gaussians &g = v.g;
@@ -227,55 +245,28 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v) {
     app[1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
     // the 4th quarter of the 64-B test record (rows of W are the first three): what a candidate test needs besides W
     const_cast<float4 *>(v.inst_w)[4 * pos + 3] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
+    if (grads) {
+        float4 *im = const_cast<float4 *>(v.inst_m) + 4 * pos;
+        im[0].w = expf(g.scale[3 * i]), im[1].w = expf(g.scale[3 * i + 1]), im[2].w = expf(g.scale[3 * i + 2]);
+        im[3] = reinterpret_cast<const float4 *>(g.rotation)[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward: one bounce step for every ray of this rank
+// forward: all bounce steps of every tile of this rank
 // ---------------------------------------------------------------------------------------------------------
-template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) k_forward(DeviceView v, int step) {
-#include "forward_decl.inc"
-    const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
-    if (step > num_bounces) return;
-
-    uint32_t w_rays = 0, w_cand = 0, w_comp = 0;
-    uint32_t cur_q = blockIdx.x & 7u;
-
-    // Quarter split (few tiles per rank, see egr_trace_launch): a wave takes 16 of a tile's 64 rays, so a heavy tile is four
-    // short tasks on four SIMDs instead of one long one. Everything per ray (state, lists, arena rows) keeps its place; the
-    // tile's arena chain becomes four chains (one per quarter, heads in task_last_block[..][quarter]).
-    const bool split = ((v.split_mask >> step) & 1u) != 0u;
-
-    for (;;) {
-        const uint32_t tq = wave_next_task(v.queues + 8 * step, split ? v.task_count * 4u : v.task_count, cur_q);
-        if (tq == 0xFFFFFFFFu) break;
-#include "forward_task.inc"
-        w_rays += active ? 1u : 0u;
-        w_cand += active ? traversed : 0u;
-        w_comp += active ? nhits : 0u;
-    }
-#ifdef EGR_TRAVERSAL_STATS
-    if (lane == 0) { // exit-time spread of the persistent waves (s_memrealtime: constant 100 MHz)
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        atomicMin(reinterpret_cast<unsigned long long *>(v.control + CW_DBG3 + 4 * step), now);
-        atomicMax(reinterpret_cast<unsigned long long *>(v.control + CW_DBG3 + 4 * step + 2), now);
-    }
-#endif
-    w_rays = wave_sum_u32(w_rays), w_cand = wave_sum_u32(w_cand), w_comp = wave_sum_u32(w_comp);
-    if (lane == 0) add64(v.control, CW_RAYS + 2 * step, w_rays), add64(v.control, CW_CAND + 2 * step, w_cand), add64(v.control, CW_COMP + 2 * step, w_comp);
-}
-
 // The fused per-tile chain: a wave takes a tile through ALL its steps (trace, step epilogue, trace, ...) before it takes the
 // next tile. A rank's forward time is then max over tiles of (sum of its steps) instead of the sum over steps of (max over
-// tiles). The launch path uses it when a rank holds few tiles per wave slot (multi-GPU partitions): every step kernel then
-// lasts as long as its heaviest tile, and a tile's cost at one step says nothing about its cost at the next.
-// Same per-step code as k_forward (forward_task.inc) and the same step epilogue as k_step_epilogue (egr_epilogue.hpp).
-template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) k_forward_chain(DeviceView v) {
+// tiles): with one kernel per step every kernel ends with a tail as long as its heaviest tile, and a tile's cost at one step
+// says nothing about its cost at the next (measured correlation -0.2 .. -0.07; round 1: 315 -> 364 Mrays/s).
+// CUBE = the exact-statistics build (egr_set_exact_stats): the tree bounds the reference's instance CUBES and every cube overlap
+// is counted, so num_traversed_per_pixel is the reference's number (see forward_task.inc); images are the same.
+template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) k_forward_chain(DeviceView v) {
 #include "forward_decl.inc"
     __shared__ uint32_t wc[3 * EGR_NSTEPS]; // this wave's ray / candidate / composited counts per step
     if (lane < 3 * EGR_NSTEPS) wc[lane] = 0u;
     __syncthreads();
     uint32_t cur_q = blockIdx.x & 7u;
-    constexpr bool split = false;
 
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues, v.task_count, cur_q);
@@ -298,57 +289,23 @@ template <bool GRADS> __global__ void __launch_bounds__(EGR_WAVE) __attribute__(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// backward: one step, walked newest (farthest) hit first  (backward_pass.cu:3-222)
+// backward: walked newest (farthest) hit first  (backward_pass.cu:3-222)
 // ---------------------------------------------------------------------------------------------------------
-// Gradient pre-reduction (cdna guide, Guideline 12): the 64 rays of a tile composite the same few dozen Gaussians,
+// Gradient pre-reduction (cdna guide, Guideline 12): the 64 primary rays of a tile composite the same few dozen Gaussians,
 // so per-hit contributions are first summed in a per-wave LDS hash table (ds_add_f32, open addressing on the
-// gaussian id) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
+// record index) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
 #define EGR_GT_SLOTS 128
 #define EGR_GT_COMPS 22
 #define EGR_GT_EMPTY 0xFFFFFFFFu
-// component order of the LDS table, of a bucket record (first 15) and of a gradient row (DeviceView::grad_rows)
+// component order of the LDS table, of a wide-add record (first 15) and of a gradient row (DeviceView::grad_rows)
 enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_WEIGHT = 14, GC_NORMAL = 15, GC_F0 = 18, GC_ROUGH = 21 };
 #define EGR_ROW_STRIDE 32 // floats per gradient row: one 128-B line per gaussian
 
-// Bounce steps: a tile's rays scatter over hundreds of distinct gaussians and the device runs at its fp32-atomic rate
-// (~26 G/s measured) if every contribution is a global atomic. Instead ONE 64-B record per (tile, gaussian) - or per hit
-// when the LDS table is full - is appended to the bucket of its gaussian (256 Morton-consecutive gaussians, one returning
-// counter atomic); k_bucket_reduce then sums each bucket in LDS and writes the gradients without global atomics.
-// Slot allocation is WAVE-AGGREGATED: the tiles of a bounce step hit neighbouring gaussians, so most lanes of one append want
-// the same bucket, and 64 returning atomics on one counter serialise in the L2 (measured: skipping the LDS table, i.e. 33 %
-// more appends, doubled the kernel time). One lane per distinct bucket adds the group's size; every lane gets base + rank.
-// All distinct buckets' atomics are in flight together (their results are only consumed after the loop).
-// Must be called by all lanes of the wave (wave-uniform control flow). Returns the record index, 0xFFFFFFFF for !need.
-EGR_DI uint32_t bucket_alloc_wave(const DeviceView &v, bool need, uint32_t bucket, uint32_t &log_used) {
-    const int lane = threadIdx.x;
-    unsigned long long M = __ballot(need);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (v.log_mode == 2) { // records go straight to the gradient rows (bucket_store_wave): nothing to allocate, only counted
-        log_used += (uint32_t)__popcll(M);
-        return need ? 0u : 0xFFFFFFFFu;
-    }
-    if (v.log_mode) { // every resident wave owns a private run of the record log: no allocation atomics at all
-        const uint32_t at = log_used + (uint32_t)__popcll(M & below);
-        log_used += (uint32_t)__popcll(M);
-        return (need && at < v.log_cap) ? at : 0xFFFFFFFFu;
-    }
-    uint32_t my_leader = 0, my_rank = 0, base_mine = 0;
-    while (M) {
-        const int L = __ffsll((long long)M) - 1;
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bucket, L);
-        const bool mine = need && bucket == b;
-        const unsigned long long S = __ballot(mine);
-        if (mine) my_leader = (uint32_t)L, my_rank = (uint32_t)__popcll(S & below);
-        if (lane == L) base_mine = atomicAdd(v.gb_count + b, (uint32_t)__popcll(S));
-        M &= ~S;
-    }
-    const uint32_t base = (uint32_t)__shfl((int)base_mine, (int)my_leader);
-    return need ? base + my_rank : 0xFFFFFFFFu;
-}
-// Direct mode: SIXTEEN LANES PER RECORD add the 15 values of every lane with `ok` to components base .. base+14 of its gaussian's
+// SIXTEEN LANES PER RECORD add the 15 values of every lane with `ok` to components base .. base+14 of its gaussian's
 // gradient row - one 64-B atomic request per record, nothing returned, so the requests drain behind the wave's arithmetic
-// instead of in a kernel of their own (a lane adding its own 15 values issues 15 x 64 scattered 4-B requests per instruction
-// row). Wave-uniform call; `stage` = 64 x 4 float4.
+// (a lane adding its own 15 values issues 15 x 64 scattered 4-B requests per instruction row; the earlier record paths -
+// per-block buckets + counting-sort reduce, per-wave record logs + an apply kernel - are measured in DESIGN.md 4 and gone).
+// Wave-uniform call; `stage` = 64 x 4 float4.
 EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const float (&r)[15], uint32_t base, float4 *stage) {
     const int lane = threadIdx.x;
     if (ok) {
@@ -370,238 +327,65 @@ EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const floa
     }
     __syncthreads();
 }
-// Writes the records of the lanes with `ok` to their bucket slots, FOUR LANES PER RECORD: a lane stages its 64-B record in LDS,
-// then in each of four passes lane L stores quarter (L & 3) of the record of lane 16 * pass + (L >> 2) - one contiguous 64-B
-// request per record instead of four 16-B requests from one lane (the write-through L1 forwards every store instruction of a
-// lane as its own L2 request, and L2 requests are what bounds the bounce backward). Wave-uniform call; `stage` = 64 x 4 float4.
-EGR_DI void bucket_store_wave(const DeviceView &v, bool ok, uint32_t pos, uint32_t at, const float (&r)[15], float4 *stage) {
-    if (v.log_mode == 2) { // GC_OPA .. GC_WEIGHT are components 0..14 of the row, in record order
-        wide_add_wave(v, ok, pos, r, 0u, stage);
-        return;
-    }
-    const int lane = threadIdx.x;
-    if (ok) {
-        stage[4 * lane + 0] = make_float4(u2f(v.log_mode ? pos : (pos & ((1u << EGR_BUCKET_SHIFT) - 1u))), r[GC_OPA], r[GC_SCALE], r[GC_SCALE + 1]);
-        stage[4 * lane + 1] = make_float4(r[GC_SCALE + 2], r[GC_MEAN], r[GC_MEAN + 1], r[GC_MEAN + 2]);
-        stage[4 * lane + 2] = make_float4(r[GC_ROT], r[GC_ROT + 1], r[GC_ROT + 2], r[GC_ROT + 3]);
-        stage[4 * lane + 3] = make_float4(r[GC_RGB], r[GC_RGB + 1], r[GC_RGB + 2], r[GC_WEIGHT]);
-    }
-    const uint32_t slot4 = ok ? (v.log_mode ? (v.log_slot0 + blockIdx.x) * v.log_cap + at : (pos >> EGR_BUCKET_SHIFT) * v.gb_cap + at) : 0xFFFFFFFFu; // record index in gb_data (x 4 float4)
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
-        const int src = 16 * pass + (lane >> 2), q = lane & 3;
-        const uint32_t d = (uint32_t)__shfl((int)slot4, src);
-        if (d != 0xFFFFFFFFu) v.gb_data[(size_t)d * 4 + q] = stage[4 * src + q];
-    }
-    __syncthreads();
-}
 
-template <int NC> EGR_DI void grad_table_flush(const DeviceView &v, bool bucketed, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane, uint32_t &log_used) {
+// Flush of the primary step's LDS table: every used slot leaves as two 16-lane records (components 0-14 and 15-21 of the row).
+EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane) {
     __syncthreads();
-    for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: the bucket allocation below is a wave-level operation
+    for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: wide_add_wave is a wave-level operation
         const int s = s0 + lane;
         const uint32_t pos = gt_keys[s];
         const bool valid = pos != EGR_GT_EMPTY;
         gt_keys[s] = EGR_GT_EMPTY;
-        float x[NC];
+        float lo[15], hi[15];
 #pragma unroll
-        for (int c = 0; c < NC; c++) x[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f, gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
-        bool stored = false;
-        if constexpr (NC == 15) { // bounce steps carry no normal / f0 / roughness gradients (backward_pass.cu:215-219)
-            if (bucketed && __ballot(valid) != 0ull) {
-                const uint32_t at = bucket_alloc_wave(v, valid, pos >> EGR_BUCKET_SHIFT, log_used);
-                stored = valid && at < (v.log_mode ? v.log_cap : v.gb_cap); // full: atomics below (correct, slower)
-                bucket_store_wave(v, stored, pos, at, x, stage);
-            }
-        }
-        if constexpr (NC == EGR_GT_COMPS) { // primary step: the row's 22 components as two 16-lane records
-            if (v.log_mode == 2 && v.wide_primary && __ballot(valid) != 0ull) {
-                float lo[15], hi[15];
+        for (int c = 0; c < 15; c++) lo[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f, gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 15; c++) lo[c] = x[c], hi[c] = (15 + c < NC) ? x[(15 + c < NC) ? 15 + c : 0] : 0.0f;
-                wide_add_wave(v, valid, pos, lo, 0u, stage);
-                wide_add_wave(v, valid, pos, hi, 15u, stage);
-                stored = valid;
-            }
+        for (int c = 0; c < 15; c++) {
+            hi[c] = 0.0f;
+            if (15 + c < EGR_GT_COMPS) hi[c] = valid ? gt_vals[(15 + c) * EGR_GT_SLOTS + s] : 0.0f, gt_vals[(15 + c) * EGR_GT_SLOTS + s] = 0.0f;
         }
-        if (valid && !stored) {
-            float *row = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE; // all components of a gaussian share one line
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (x[c] != 0.0f) atomicAdd(row + c, x[c]);
-        }
+        if (__ballot(valid) == 0ull) continue;
+        wide_add_wave(v, valid, pos, lo, 0u, stage);
+        wide_add_wave(v, valid, pos, hi, 15u, stage);
     }
     __syncthreads();
-}
-
-// PRIMARY = step 0 (22 gradient components, coherent tiles, no buckets); the bounce instantiation drops the normal / f0 /
-// roughness chains and their registers.
-template <bool PRIMARY> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward(DeviceView v, int step_arg) {
-    const int step = PRIMARY ? 0 : step_arg;
-    const int lane = threadIdx.x;
-    constexpr int NC = PRIMARY ? EGR_GT_COMPS : (int)GC_NORMAL; // gradient components of this instantiation (22 / 15)
-    __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
-    __shared__ float gt_vals[NC * EGR_GT_SLOTS];
-    __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (bucket_store_wave / wide_add_wave)
-    for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
-    for (int s = lane; s < NC * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
-    __syncthreads();
-    const float exp_power = *v.cfg.exp_power;
-    const float eps_scale_grad = *v.cfg.eps_scale_grad;
-    const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
-    if (step > num_bounces) return;
-    const egr_gaussians &g = v.g;
-    uint32_t cur_q = blockIdx.x & 7u;
-    const bool bucketed = !PRIMARY && v.gb_data != nullptr;
-    uint32_t log_used = (bucketed && v.log_mode == 1) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u; // records this wave slot has logged so far
-
-    for (;;) {
-        const uint32_t tq = wave_next_task(v.queues + 8 * (3 + step), v.task_count, cur_q);
-        if (tq == 0xFFFFFFFFu) break;
-#include "backward_task.inc"
-    }
-    if (bucketed && v.log_mode == 1 && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
-    if (bucketed && v.log_mode == 2 && lane == 0 && log_used) atomicAdd(v.control + CW_BUCKET_RECORDS, log_used);
 }
 
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
-// last bounce first, then the primary step (22 components, no records). Same per-step code as k_backward (backward_task.inc).
+// last bounce first (15 gradient components per hit, straight out as wide adds), then the primary step (22 components through
+// the LDS table). Per-step code: backward_task.inc.
 __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward_chain(DeviceView v) {
     const int lane = threadIdx.x;
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
     __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
-    __shared__ float4 stage[4 * EGR_WAVE];
+    __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (wide_add_wave)
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < EGR_GT_COMPS * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
     __syncthreads();
     const float exp_power = *v.cfg.exp_power;
     const float eps_scale_grad = *v.cfg.eps_scale_grad;
     const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
-    const egr_gaussians &g = v.g;
     uint32_t cur_q = blockIdx.x & 7u;
-    const bool records = v.gb_data != nullptr;
-    uint32_t log_used = (records && v.log_mode == 1) ? v.gb_count[v.log_slot0 + blockIdx.x] : 0u;
+    uint32_t records = 0u; // wide-add records this wave sent from bounce steps (egr_counters::bucket_records)
 
     for (;;) {
-        const uint32_t tq = wave_next_task(v.queues + 8 * 3, v.task_count, cur_q);
+        const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
         for (int step = num_bounces; step >= 1; step--) {
             constexpr bool PRIMARY = false;
-            constexpr int NC = (int)GC_NORMAL;
-            const bool bucketed = records;
             do {
 #include "backward_task.inc"
             } while (false);
         }
         {
             constexpr bool PRIMARY = true;
-            constexpr int NC = EGR_GT_COMPS;
             const int step = 0;
-            const bool bucketed = false;
             do {
 #include "backward_task.inc"
             } while (false);
         }
     }
-    if (records && v.log_mode == 1 && lane == 0) v.gb_count[v.log_slot0 + blockIdx.x] = min(log_used, v.log_cap);
-    if (records && v.log_mode == 2 && lane == 0 && log_used) atomicAdd(v.control + CW_BUCKET_RECORDS, log_used);
-}
-
-// Second half of the bucketed bounce backward: one workgroup per bucket sums the bucket's records in LDS (ds_add_f32) and
-// adds the totals to the gradient tensors with plain read-modify-writes (a gaussian belongs to exactly one bucket and
-// no other kernel touches the gradients concurrently - stream order).
-#define EGR_BUCKET_SLICE 2048u // records one workgroup sums; heavy buckets (scene centre) are split over blockIdx.y
-// `ds_add_f32` retires about one lane per clock on this part, so summing 15 components per record with LDS float atomics
-// (first version: 2.0 ms for 25 M records) is bound by the LDS atomic unit. This version counting-sorts the slice's record
-// indices by gaussian with ONE returning integer atomic per record, then thread t sums the records of gaussian t in
-// registers (no float atomics), and the totals leave through LDS so that the gradient rows are written coalesced.
-__global__ void __launch_bounds__(1 << EGR_BUCKET_SHIFT) k_bucket_reduce(DeviceView v) {
-    constexpr int BG = 1 << EGR_BUCKET_SHIFT;          // gaussians per bucket (= threads per workgroup)
-    constexpr int PER = (int)(EGR_BUCKET_SLICE / (uint32_t)BG); // records per thread
-    static_assert(BG <= 1024 && EGR_BUCKET_SLICE % BG == 0, "one thread per gaussian of the bucket");
-    __shared__ uint32_t hist[BG], start[BG];
-    __shared__ uint16_t order[EGR_BUCKET_SLICE];
-    __shared__ float acc[BG * 17]; // [gaussian][15 components], row padded to 17 words
-    const uint32_t bucket = blockIdx.x;
-    const uint32_t count = min(v.gb_count[bucket], v.gb_cap);
-    const uint32_t begin = blockIdx.y * EGR_BUCKET_SLICE;
-    if (begin >= count) return;
-    const uint32_t n = min(count - begin, EGR_BUCKET_SLICE);
-    const bool shared_bucket = count > EGR_BUCKET_SLICE; // several workgroups add into the same rows
-    const int tid = threadIdx.x;
-    if (tid == 0) atomicAdd(v.control + CW_BUCKET_RECORDS, n);
-    const float4 *src = v.gb_data + ((size_t)bucket * v.gb_cap + begin) * 4;
-    hist[tid] = 0u;
-    __syncthreads();
-    uint32_t key[PER], rank[PER];
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const uint32_t r = (uint32_t)tid + (uint32_t)BG * (uint32_t)k;
-        key[k] = r < n ? (f2u(reinterpret_cast<const float *>(src + 4 * (size_t)r)[0]) & (uint32_t)(BG - 1)) : 0u;
-        rank[k] = r < n ? atomicAdd(&hist[key[k]], 1u) : 0u;
-    }
-    __syncthreads();
-    const uint32_t mine = hist[tid];
-    { // exclusive prefix sum of hist over the 256 gaussians (Hillis-Steele in LDS)
-        start[tid] = mine;
-        __syncthreads();
-        for (int off = 1; off < BG; off <<= 1) {
-            const uint32_t add = tid >= off ? start[tid - off] : 0u;
-            __syncthreads();
-            start[tid] += add;
-            __syncthreads();
-        }
-    }
-    const uint32_t first = start[tid] - mine; // inclusive -> exclusive
-    __syncthreads();
-    start[tid] = first;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const uint32_t r = (uint32_t)tid + (uint32_t)BG * (uint32_t)k;
-        if (r < n) order[start[key[k]] + rank[k]] = (uint16_t)r;
-    }
-    __syncthreads();
-    float s[15];
-#pragma unroll
-    for (int c = 0; c < 15; c++) s[c] = 0.0f;
-    for (uint32_t i = 0; i < mine; i++) { // the records of gaussian `tid`
-        const float4 *rec = src + 4 * (size_t)order[first + i];
-        const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
-        s[0] += a.y, s[1] += a.z, s[2] += a.w, s[3] += b.x, s[4] += b.y, s[5] += b.z, s[6] += b.w;
-        s[7] += c.x, s[8] += c.y, s[9] += c.z, s[10] += c.w, s[11] += d.x, s[12] += d.y, s[13] += d.z, s[14] += d.w;
-    }
-#pragma unroll
-    for (int c = 0; c < 15; c++) acc[17 * tid + c] = s[c];
-    __syncthreads();
-    // 16 consecutive threads write the first 64 B of one gradient row: coalesced, no scatter over the gradient tensors
-    for (int i = tid; i < BG * 16; i += BG) {
-        const uint32_t l = (uint32_t)i >> 4, cidx = (uint32_t)i & 15u, pos = bucket * BG + l;
-        if (cidx >= 15u || pos >= v.n) continue;
-        const float x = acc[17 * l + cidx];
-        if (x == 0.0f) continue;
-        float *dst = v.grad_rows + (size_t)pos * EGR_ROW_STRIDE + cidx;
-        if (shared_bucket) atomicAdd(dst, x);
-        else *dst += x;
-    }
-}
-
-// Log mode (EGR_BUCKETED_BACKWARD=2, the default): every resident wave appends its records to a private run of the record log -
-// no slot allocation at all in k_backward (the per-bucket counters cost one returning atomic per distinct bucket and append:
-// bounce backward 2.4 + 1.8 ms -> 1.3 + 1.4 ms) - and this kernel applies them: 16 lanes per record, ONE 64-B atomic request to
-// the gaussian's gradient row (1.4 ms for 25 M records, against 0.6 ms for the counting-sort reduce of the bucket mode).
-__global__ void __launch_bounds__(256) k_log_apply(DeviceView v) {
-    const uint32_t slot = v.log_slot0 + blockIdx.x; // wave slot of this strand
-    const uint32_t count = min(v.gb_count[slot], v.log_cap);
-    const float *recs = reinterpret_cast<const float *>(v.gb_data) + (size_t)slot * v.log_cap * 16;
-    if (threadIdx.x == 0 && count) atomicAdd(v.control + CW_BUCKET_RECORDS, count);
-    for (uint32_t i = threadIdx.x; i < count * 16u; i += 256u) {
-        const float x = recs[i];
-        const uint32_t c = i & 15u;
-        const uint32_t pos = f2u(__shfl(x, (int)(threadIdx.x & 63u) & ~15)); // word 0 of the record
-        if (c != 0u && x != 0.0f) atomicAdd(v.grad_rows + (size_t)pos * EGR_ROW_STRIDE + (c - 1u), x);
-    }
+    if (lane == 0 && records) atomicAdd(v.control + CW_BUCKET_RECORDS, records);
 }
 
 // Last backward kernel: one thread per gaussian id adds its gradient row (a 128-B line at its record position) to the
@@ -691,8 +475,6 @@ template <class T> void dfree(T *&p) {
 
 } // namespace
 
-void egr_launch_step_epilogue(const DeviceView &v, int step, bool grads, hipStream_t s); // epilogue.hip
-
 uint32_t egr_num_tasks_for_rank(const egr_context *c) {
     uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
     uint32_t M = mtx * mty;
@@ -723,7 +505,7 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->gb_data), dfree(c->gb_count), dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
+    dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
     for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -740,12 +522,9 @@ void egr_trace_alloc(egr_context *c) {
     c->num_tasks_total = 4u * mtx * mty;
     hipDeviceProp_t prop;
     EGR_HIP(hipGetDeviceProperties(&prop, c->device));
-    int per_cu_g = 0, per_cu_n = 0;
-    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, k_forward<true>, EGR_WAVE, 0));
-    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_n, k_forward<false>, EGR_WAVE, 0));
-    int per_cu_c = 0; // the chain kernels are built for four waves per SIMD (they are faster with more waves in flight even with spills)
-    if (c->chain_mode != 0) EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_c, k_forward_chain<true>, EGR_WAVE, 0));
-    int per_cu = std::max(1, std::min(32, std::max(std::max(per_cu_g, per_cu_n), per_cu_c)));
+    int per_cu = 0; // the forward chain is built for four waves per SIMD (faster with more waves in flight even with spills)
+    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_forward_chain<true, false>, EGR_WAVE, 0));
+    per_cu = std::max(1, std::min(32, per_cu));
     if (const char *e = getenv("EGR_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // tuning knob
     uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
@@ -762,20 +541,19 @@ void egr_trace_alloc(egr_context *c) {
     EGR_HIP(hipMalloc((void **)&c->ext_keys, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float)));
     EGR_HIP(hipMalloc((void **)&c->ext_vals, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float2)));
     EGR_HIP(hipMalloc((void **)&c->stack_spill, S * c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
-    double bwd_bytes = (double)c->bwd_capacity * 36.0;
-    if (c->bucketed_backward == 1 || c->bucketed_backward == 2) bwd_bytes *= 0.25; // the rest holds the gradient buckets / record logs (mode 3 stores no records)
+    const double bwd_bytes = (double)c->bwd_capacity * 36.0; // the reference's ppll_backward_size entries x 36 B: all of it is arena
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
     EGR_HIP(hipMalloc((void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
-    EGR_HIP(hipMalloc((void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * 4 * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * sizeof(uint32_t)));
     c->state_stride = c->num_tasks_total * EGR_WAVE;
     EGR_HIP(hipMalloc((void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
     EGR_HIP(hipMemset(c->state, 0, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
     EGR_HIP(hipMalloc((void **)&c->control, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipMemset(c->control, 0, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipHostMalloc((void **)&c->control_host, CW_COUNT * sizeof(uint32_t)));
-    EGR_HIP(hipMalloc((void **)&c->queues, 48 * S * sizeof(uint32_t)));
-    EGR_HIP(hipMemset(c->queues, 0, 48 * S * sizeof(uint32_t)));
+    EGR_HIP(hipMalloc((void **)&c->queues, EGR_QUEUE_WORDS * S * sizeof(uint32_t)));
+    EGR_HIP(hipMemset(c->queues, 0, EGR_QUEUE_WORDS * S * sizeof(uint32_t)));
     if (c->strands > 1) {
         EGR_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < c->strands; i++) {
@@ -785,22 +563,6 @@ void egr_trace_alloc(egr_context *c) {
     }
     EGR_HIP(hipMalloc((void **)&c->task_macro, std::max<size_t>(c->num_tasks_total / 4, 1) * sizeof(uint32_t)));
     egr_build_task_order(c);
-}
-
-// Bucket storage for the bounce-step backward: half of the backward byte budget (ppll_backward_size x 36 B), split
-// evenly over the buckets; a bucket that overflows falls back to atomics for the excess (correct, slower).
-void egr_trace_reserve_buckets(egr_context *c, uint32_t n) {
-    const uint32_t nb = (n + (1u << EGR_BUCKET_SHIFT) - 1u) >> EGR_BUCKET_SHIFT;
-    if (!c->bucketed_backward || nb == 0) return;
-    if (nb <= c->gb_buckets_alloc && c->gb_data) return;
-    dfree(c->gb_data), dfree(c->gb_count);
-    const uint32_t nb_alloc = nb + nb / 8 + 1;
-    const double bytes = c->bucketed_backward == 3 ? 0.0 : (double)c->bwd_capacity * 36.0 * 0.75; // mode 3 adds records to the rows directly: a token allocation
-    uint64_t cap = (uint64_t)(bytes / 64.0 / (double)nb_alloc);
-    c->gb_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 1u << 22);
-    EGR_HIP(hipMalloc((void **)&c->gb_data, (size_t)nb_alloc * c->gb_cap * 64));
-    EGR_HIP(hipMalloc((void **)&c->gb_count, std::max<size_t>(nb_alloc, (size_t)c->num_slots * 4) * sizeof(uint32_t)));
-    c->gb_buckets_alloc = nb_alloc;
 }
 
 DeviceView egr_make_view(const egr_context *c) {
@@ -820,15 +582,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.ext_keys = c->ext_keys, v.ext_vals = c->ext_vals, v.ext_blocks_cap = c->ext_blocks_cap;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
-    v.packet_mode = c->packet_mode, v.packet_cos_min = c->packet_cos_min, v.packet_origin_max = c->packet_origin_max;
-    v.group_walk = c->group_walk;
-    v.bounce_table = c->bounce_table;
-    v.wide_primary = c->wide_primary;
-    v.split_mask = 0u;
-    v.gb_data = c->gb_data, v.gb_count = c->gb_count, v.gb_cap = c->gb_cap;
-    v.log_mode = c->bucketed_backward == 2 ? 1 : c->bucketed_backward == 3 ? 2 : 0, v.log_slot0 = 0; // 1: per-wave logs + k_log_apply, 2: direct
-    v.log_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->gb_buckets_alloc * c->gb_cap / std::max<uint64_t>((uint64_t)c->num_slots * (uint64_t)c->strands, 1), 1u << 24);
-    if (v.log_mode == 2) v.log_cap = std::max(v.log_cap, 1u); // (nothing is stored in this mode; a record is `stored` when at = 0 < log_cap)
+    v.cube_mode = c->exact_stats ? 1 : 0;
     return v;
 }
 
@@ -839,18 +593,13 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
     hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
     EGR_HIP(hipMemsetAsync(c->stats.num_accumulated_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s)); // stats.h:25-28
     EGR_HIP(hipMemsetAsync(c->stats.num_traversed_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s));
-    if (v.n) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v);
+    if (v.n) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v, grads ? 1 : 0);
     egr_stamp_end(c, s);
-    static const char *fn[3] = {"forward_step0", "forward_step1", "forward_step2"};
-    static const char *bn[3] = {"backward_step0", "backward_step1", "backward_step2"};
-    const uint32_t nbuckets = (v.n + (1u << EGR_BUCKET_SHIFT) - 1u) >> EGR_BUCKET_SHIFT;
     if (v.num_tasks) {
-        if (grads && v.gb_data && nbuckets)
-            EGR_HIP(hipMemsetAsync(v.gb_count, 0, (v.log_mode ? (size_t)c->num_slots * c->strands : (size_t)nbuckets) * sizeof(uint32_t), s));
-        // Strands: slices of the task order (whole macro tiles), each with its own queues and scratch slots, each running the
-        // step kernels in order on its own stream. Tiles only depend on their own earlier steps, so strands never synchronise
-        // with each other until the join; while one strand's kernel drains its last long tiles the next kernel of another
-        // strand takes the freed wave slots.
+        // Strands: slices of the task order (whole macro tiles), each with its own queues and scratch slots, each running its
+        // two chain kernels in order on its own stream. Tiles only depend on their own earlier steps, so strands never
+        // synchronise with each other until the join; while one strand's kernel drains its last long tiles the next kernel of
+        // another strand takes the freed wave slots.
         // (no explicit egr_set_strands: all strands when the rank has at least four tiles per wave slot; with fewer - a rank of a
         // multi-GPU partition - concurrent chains only delay each other's heaviest tiles: 4.66 / 4.85 / 4.97 ms with 1 / 2 / 3
         // strands for rank 0 of an 8-way partition, 18.7 / 18.3 / 18.0 ms for the whole image)
@@ -864,57 +613,24 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             const uint32_t groups = v.num_tasks / 4u; // tasks come in groups of 4 (one macro tile)
             w.task_begin = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)st) / (uint64_t)S);
             w.task_count = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)(st + 1)) / (uint64_t)S) - w.task_begin;
-            w.queues = c->queues + 48 * st;
+            w.queues = c->queues + EGR_QUEUE_WORDS * st;
             const size_t slot0 = (size_t)st * c->num_slots;
             w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE, w.cand_queue += slot0 * c->cand_cap * EGR_WAVE;
             w.stack_spill += slot0 * EGR_GSTK * EGR_WAVE;
-            w.log_slot0 = (uint32_t)slot0;
             const dim3 sgrid(std::max(1u, std::min(c->num_slots, w.task_count)));
-            // Few tiles per wave slot (a rank of a multi-GPU partition): the step time is the latency of the heaviest tiles, not
-            // the throughput of the chip. The bounce steps then run as quarter tiles (16 rays per wave, see k_forward).
-            const bool split = c->group_walk && (c->split_mode == 1 || (c->split_mode < 0 && (double)w.task_count < c->split_below * (double)c->num_slots));
-            w.split_mask = split ? 0x6u : 0u; // steps 1, 2
-            const dim3 qgrid(std::max(1u, std::min(c->num_slots, w.task_count * 4u)));
-            // Few tiles per wave slot: every step kernel lasts as long as its heaviest tile, and a tile's cost at one step says
-            // nothing about its cost at the next (measured correlation -0.2 .. -0.07): run the fused per-tile chain.
-            const bool chain = !split && (c->chain_mode == 1 || (c->chain_mode < 0 && (double)w.task_count < c->chain_below * (double)c->num_slots));
-            if (chain) {
-                egr_stamp_begin(c, "forward_chain", ls);
-                if (grads) hipLaunchKernelGGL(k_forward_chain<true>, sgrid, block, 0, ls, w);
-                else hipLaunchKernelGGL(k_forward_chain<false>, sgrid, block, 0, ls, w);
-                egr_stamp_end(c, ls);
+            egr_stamp_begin(c, "forward_chain", ls);
+            if (grads) {
+                if (v.cube_mode) hipLaunchKernelGGL((k_forward_chain<true, true>), sgrid, block, 0, ls, w);
+                else hipLaunchKernelGGL((k_forward_chain<true, false>), sgrid, block, 0, ls, w);
+            } else {
+                if (v.cube_mode) hipLaunchKernelGGL((k_forward_chain<false, true>), sgrid, block, 0, ls, w);
+                else hipLaunchKernelGGL((k_forward_chain<false, false>), sgrid, block, 0, ls, w);
             }
-            for (int step = 0; step < EGR_NSTEPS && !chain; step++) {
-                egr_stamp_begin(c, fn[step], ls);
-                const dim3 fgrid = ((w.split_mask >> step) & 1u) ? qgrid : sgrid;
-                if (grads) hipLaunchKernelGGL(k_forward<true>, fgrid, block, 0, ls, w, step);
-                else hipLaunchKernelGGL(k_forward<false>, fgrid, block, 0, ls, w, step);
-                egr_launch_step_epilogue(w, step, grads, ls);
-                egr_stamp_end(c, ls);
-            }
-            if (grads && chain) {
+            egr_stamp_end(c, ls);
+            if (grads) {
                 egr_stamp_begin(c, "backward_chain", ls);
                 hipLaunchKernelGGL(k_backward_chain, sgrid, block, 0, ls, w);
                 egr_stamp_end(c, ls);
-                if (w.gb_data && nbuckets && w.log_mode == 1) {
-                    egr_stamp_begin(c, "backward_bucket_reduce", ls);
-                    hipLaunchKernelGGL(k_log_apply, dim3(c->num_slots), dim3(256), 0, ls, w);
-                    egr_stamp_end(c, ls);
-                }
-            } else if (grads) {
-                for (int step = EGR_NSTEPS - 1; step >= 0; step--) { // shaders.cu:157
-                    egr_stamp_begin(c, bn[step], ls);
-                    if (step == 0) hipLaunchKernelGGL(k_backward<true>, sgrid, block, 0, ls, w, step);
-                    else hipLaunchKernelGGL(k_backward<false>, sgrid, block, 0, ls, w, step);
-                    egr_stamp_end(c, ls);
-                    if (step == 1 && w.gb_data && nbuckets && w.log_mode == 1) {
-                        // the strand's bounce records are complete: apply them now, on the strand's stream - the kernel is bound by
-                        // atomic requests, not by the CUs, and overlaps with the other strand's kernels
-                        egr_stamp_begin(c, "backward_bucket_reduce", ls);
-                        hipLaunchKernelGGL(k_log_apply, dim3(c->num_slots), dim3(256), 0, ls, w);
-                        egr_stamp_end(c, ls);
-                    }
-                }
             } else {
                 egr_stamp_begin(c, "write_outputs", ls);
                 hipLaunchKernelGGL(k_finish, dim3(std::max(1u, std::min(w.task_count, 65535u))), block, 0, ls, w);
@@ -925,22 +641,13 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
                 EGR_HIP(hipStreamWaitEvent(s, c->ev_join[st], 0));
             }
         }
-        if (grads) {
-            if (v.gb_data && nbuckets && !v.log_mode) { // one reduce for both bounce steps of all strands
-                egr_stamp_begin(c, "backward_bucket_reduce", s);
-                const uint32_t slices = (v.gb_cap + EGR_BUCKET_SLICE - 1u) / EGR_BUCKET_SLICE;
-                hipLaunchKernelGGL(k_bucket_reduce, dim3(nbuckets, slices), dim3(1u << EGR_BUCKET_SHIFT), 0, s, v);
-                egr_stamp_end(c, s);
-            }
-            if (v.n) {
-                egr_stamp_begin(c, "backward_grad_gather", s);
-                hipLaunchKernelGGL(k_grad_gather, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
-                egr_stamp_end(c, s);
-            }
+        if (grads && v.n) {
+            egr_stamp_begin(c, "backward_grad_gather", s);
+            hipLaunchKernelGGL(k_grad_gather, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
+            egr_stamp_end(c, s);
         }
     }
     hipLaunchKernelGGL(k_epilogue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
-    EGR_HIP(hipMemcpyAsync(c->control_host, c->control, CW_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 }
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s) {

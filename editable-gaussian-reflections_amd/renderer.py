@@ -8,7 +8,8 @@ fov = FoVy, ZNEAR/ZFAR env overrides, export order, targets CHW -> HWC, zero tar
 grad mode or forced, raytrace, optional denoise, gradient import by add_.
 
 Additions for the MI355X build: `rank` / `world_size` (image-tile partition) and
-`all_reduce_grads()` which sums the flat [22N] gradient buffer over ranks with ONE RCCL all-reduce.
+`all_reduce_grads()` which sums THIS launch's [22N] gradient contribution over ranks with ONE RCCL all-reduce
+(`parallel.all_reduce_launch_delta`) and folds it into the persistent gradient buffer.
 """
 import os
 from types import SimpleNamespace
@@ -17,6 +18,7 @@ import numpy as np
 import torch
 
 from . import make_raytracer
+from .parallel import all_reduce_launch_delta
 
 
 class GaussianParams:
@@ -55,10 +57,15 @@ class GaussianRaytracer:
             kw["ppll_forward_size"] = int(ppll_forward_size)
         if ppll_backward_size is not None:
             kw["ppll_backward_size"] = int(ppll_backward_size)
-        self.cuda_module = make_raytracer(image_width, image_height, pc.get_scaling.shape[0], **kw)
+        n = pc.get_scaling.shape[0]
+        self.cuda_module = make_raytracer(image_width, image_height, n, **kw)
+        if self.cuda_module.get_gaussians().mean.shape[0] != n:  # n == 0: the native holder starts with count = 1 (core/gaussians.h:31)
+            self.cuda_module.resize(n)
         self.rank, self.world_size = rank, world_size
+        self.import_grads = True  # False: a fused host step (trainer.FusedTrainStep) imports the raytracer gradients itself
         if world_size > 1:
             self.cuda_module.set_partition(rank, world_size)
+            self.cuda_module.use_grad_delta(True)  # launches accumulate into a per-launch buffer: see all_reduce_grads
         config = self.cuda_module.get_config()  # gaussian_raytracer.py:16-25
         config.loss_weight_diffuse.fill_(pc.cfg.loss_weight_diffuse)
         config.loss_weight_specular.fill_(pc.cfg.loss_weight_specular)
@@ -102,12 +109,19 @@ class GaussianRaytracer:
 
     @torch.no_grad()
     def all_reduce_grads(self):
-        """Multi-GPU exchange step: sum the per-Gaussian gradients + total_weight of all ranks with a
-        single all-reduce over the contiguous [22N] buffer (88 MB at N=1M). No-op for world_size == 1."""
-        if self.world_size > 1:
-            import torch.distributed as dist
+        """Multi-GPU exchange step: the launch accumulated this rank's gradients + weights into the zeroed
+        per-launch buffer `grad_delta` ([22N], 88 MB at N=1M); ONE all-reduce sums it over the ranks, then it is added to
+        the persistent `grad_flat` (whose total_weight tail lives across a whole pruning interval) and emptied. No-op when
+        the tracer is not partitioned."""
+        g = self.cuda_module.get_gaussians()
+        if g.grad_delta.numel():
+            all_reduce_launch_delta(g.grad_flat, g.grad_delta)
 
-            dist.all_reduce(self.cuda_module.get_gaussians().grad_flat, op=dist.ReduceOp.SUM)
+    def _set_full_image(self, full):
+        """No-grad renders produce images: a partitioned tracer then traces the WHOLE image on every rank (each rank would
+        otherwise only write the pixels of its own tiles and hand back stale data for the rest)."""
+        if self.world_size > 1:
+            self.cuda_module.set_partition(0 if full else self.rank, 1 if full else self.world_size)
 
     @staticmethod
     def blender_rotation(R):
@@ -135,14 +149,20 @@ class GaussianRaytracer:
                     buf.copy_(val.moveaxis(0, -1))  # CHW -> HWC (gaussian_raytracer.py:109-137)
                 else:
                     buf.zero_()
-        if torch.is_grad_enabled() or force_update_bvh:
+        grads = torch.is_grad_enabled()
+        if grads or force_update_bvh:
             self.cuda_module.update_bvh()
+        if not grads:
+            self._set_full_image(True)
         self.cuda_module.raytrace()
+        if not grads:
+            self._set_full_image(False)
         if denoise:
             self.cuda_module.denoise()
-        if torch.is_grad_enabled():
+        if grads:
             self.all_reduce_grads()
-            self._import_param_gradients()
+            if self.import_grads:
+                self._import_param_gradients()
         return {"render": framebuffer.output_rgb.clone()}
 
 

@@ -46,8 +46,37 @@ class FusedTrainStep:
         self.beta1, self.beta2, self.eps, self.scale_decay = beta1, beta2, eps, scale_decay
         self.xyz_schedule = xyz_schedule
         self.steps = 0
+        self.group_steps = {name: 0 for name, _, _ in GROUPS}  # torch.optim.Adam keeps one step count per parameter tensor
         self.exp_avg = {name: torch.zeros_like(getattr(pc, attr)) for name, attr, _ in GROUPS}
         self.exp_avg_sq = {name: torch.zeros_like(getattr(pc, attr)) for name, attr, _ in GROUPS}
+        # the fused kernel adds the raytracer-side gradients itself: GaussianRaytracer.__call__ must not import them as well
+        # (it would count them twice: g = model_grad + 2 * rt_grad)
+        raytracer.import_grads = False
+
+    # ---- optimizer surgery, mirroring scene/gaussian_model.py (the moments follow the parameters through topology changes)
+    @torch.no_grad()
+    def prune(self, keep_mask):
+        """gaussian_model.py `_prune_optimizer`: keep the rows of both moments where `keep_mask` is True. The caller prunes the
+        parameters themselves and calls raytracer.rebuild_bvh()."""
+        for name in self.exp_avg:
+            self.exp_avg[name] = self.exp_avg[name][keep_mask].contiguous()
+            self.exp_avg_sq[name] = self.exp_avg_sq[name][keep_mask].contiguous()
+
+    @torch.no_grad()
+    def extend(self, n_new):
+        """gaussian_model.py `cat_tensors_to_optimizer` (add_farfield_points): new rows start with zero moments."""
+        for name in self.exp_avg:
+            z = self.exp_avg[name].new_zeros((n_new,) + tuple(self.exp_avg[name].shape[1:]))
+            self.exp_avg[name] = torch.cat([self.exp_avg[name], z], 0)
+            self.exp_avg_sq[name] = torch.cat([self.exp_avg_sq[name], z.clone()], 0)
+
+    @torch.no_grad()
+    def reset_state(self, name):
+        """gaussian_model.py `replace_tensor_to_optimizer`: zero moments of one group (its parameter was replaced)."""
+        attr = {n: a for n, a, _ in GROUPS}[name]
+        self.exp_avg[name] = torch.zeros_like(getattr(self.pc, attr))
+        self.exp_avg_sq[name] = torch.zeros_like(getattr(self.pc, attr))
+        self.group_steps[name] = 0
 
     def update_learning_rate(self, iteration):  # gaussian_model.py:349-355
         if self.xyz_schedule is not None:
@@ -58,6 +87,8 @@ class FusedTrainStep:
     def step(self):
         g = self.rt.cuda_module.get_gaussians()
         self.steps += 1
+        for name in self.group_steps:
+            self.group_steps[name] += 1
         params = [getattr(self.pc, attr) for _, attr, _ in GROUPS]
         grads = [getattr(self.pc, attr).grad for _, attr, _ in GROUPS]
         rt_params = [getattr(g, rt) for _, _, rt in GROUPS]
@@ -66,4 +97,4 @@ class FusedTrainStep:
             params, grads, rt_params, rt_grads, [self.exp_avg[n] for n, _, _ in GROUPS], [self.exp_avg_sq[n] for n, _, _ in GROUPS],
             [self.lrs[n] for n, _, _ in GROUPS], [CLAMPS.get(n, (-math.inf, math.inf))[0] for n, _, _ in GROUPS],
             [CLAMPS.get(n, (-math.inf, math.inf))[1] for n, _, _ in GROUPS], [self.scale_decay if n == "scaling" else 1.0 for n, _, _ in GROUPS],
-            self.steps, self.beta1, self.beta2, self.eps)
+            self.steps, self.beta1, self.beta2, self.eps, [self.group_steps[n] for n, _, _ in GROUPS])

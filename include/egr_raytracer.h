@@ -91,19 +91,20 @@ typedef struct egr_metadata {
 /* core/stats.h:3-6 */
 typedef struct egr_stats {
     int32_t *num_accumulated_per_pixel; /* [H,W] composited hits of the LAST executed step (forward_pass.cu:140) */
-    int32_t *num_traversed_per_pixel;   /* [H,W] intersection-program invocations, all steps (forward_pass.cu:46) */
+    int32_t *num_traversed_per_pixel;   /* [H,W] intersection-program invocations, all steps (forward_pass.cu:46); the evaluated
+                                         * subset unless egr_set_exact_stats is on (see there) */
 } egr_stats;
 
 /* Whole-launch work counters (not in the reference; used for the roofline's algorithmic bytes). */
 typedef struct egr_counters {
     uint64_t rays[EGR_NUM_STEPS];        /* rays traced per bounce step (a ray = one pixel x step)            */
-    uint64_t candidates[EGR_NUM_STEPS];  /* cube-overlap candidates per step (Hc = intersection invocations) */
+    uint64_t candidates[EGR_NUM_STEPS];  /* candidates per step: evaluated subset, or Hc = cube overlaps with exact stats */
     uint64_t composited[EGR_NUM_STEPS];  /* composited hits per step (Kc)                                     */
     uint64_t lifetime_rays;              /* rays of ALL launches since egr_create / egr_reset_lifetime_counters */
     uint32_t lifetime_launches;
     uint32_t status;                     /* EGR_STATUS_* bit mask of the last launch                          */
     uint32_t bvh_depth;
-    uint32_t bucket_records;             /* gradient records the bounce-step backward appended (grad launches) */
+    uint32_t bucket_records;             /* 64-B gradient records the bounce-step backward added to the rows (grad launches) */
 } egr_counters;
 
 #define EGR_STATUS_OK 0u
@@ -147,6 +148,14 @@ int egr_denoise(egr_context *ctx, void *hip_stream);
 /* Multi-GPU image partition (not in the reference): this context only traces the 16x16-pixel
  * macro tiles with (tile_index % world_size) == rank; default rank 0 of 1 = whole image. */
 int egr_set_partition(egr_context *ctx, int rank, int world_size);
+
+/* Exact statistics (not in the reference). By default the tree bounds each Gaussian's ELLIPSOID and the walk evaluates only the
+ * instances whose response point can be accepted, so stats.num_traversed_per_pixel and egr_counters.candidates count that
+ * evaluated SUBSET of the reference's intersection-program invocations (shaders.cu:33) - every other output is unaffected.
+ * With enable != 0 the next egr_update_bvh / egr_rebuild_bvh bounds the instance CUBES (what OptiX's TLAS holds) and every launch
+ * counts exactly the instances whose unit cube the ray segment overlaps: the reference's number, at a slower walk. egr_raytrace
+ * fails if the flag changed since the last refit. Used by tests and by bench.py to measure Hc. */
+int egr_set_exact_stats(egr_context *ctx, int enable);
 
 /* Strands (not in the reference): egr_raytrace cuts this context's tiles into `strands` slices and runs their step kernels on
  * separate internal HIP streams (forked from / joined to the caller's stream), so that one slice's persistent-wave tail is
@@ -200,8 +209,10 @@ typedef struct egr_param_group {
     float lr;           /* this iteration's learning rate of the group                                      */
     float clamp_min, clamp_max; /* applied after the update (-INFINITY / +INFINITY: none)                    */
     float log_decay;    /* != 1: param = log(exp(param) * log_decay) before the update (scale decay)        */
+    uint32_t step;      /* this group's own 1-based Adam step count; 0: use the `step` argument             */
 } egr_param_group;
-/* `step` is Adam's 1-based step count of THIS update. Asynchronous on the stream. Returns 0 on success. */
+/* `step` is Adam's 1-based step count of THIS update (torch keeps one per parameter tensor: a group whose state was re-created
+ * - gaussian_model.py replace_tensor_to_optimizer - passes its own count in egr_param_group.step). Asynchronous on the stream. Returns 0 on success. */
 int egr_fused_adam_step(int device, const egr_param_group *groups, int num_groups, uint32_t n, uint32_t step, double beta1, double beta2,
                         double eps, void *hip_stream);
 const char *egr_fused_step_last_error(void);

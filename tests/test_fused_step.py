@@ -126,4 +126,4 @@ def test_fused_step_full_size_timing():
     print(f"host step at N=1M: fused {t_fused:.3f} ms vs stock torch sequence {t_torch:.3f} ms")
     assert t_fused < t_torch
     with pytest.raises(RuntimeError):
-        torch.ops.egr.fused_adam_step([pc._xyz], [pc._xyz.grad], [], [], [], [], [1.0], [-math.inf], [math.inf], [1.0], 1, 0.9, 0.999, 1e-15)
+        torch.ops.egr.fused_adam_step([pc._xyz], [pc._xyz.grad], [], [], [], [], [1.0], [-math.inf], [math.inf], [1.0], 1, 0.9, 0.999, 1e-15, [])

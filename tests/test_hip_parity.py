@@ -15,65 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-PKG = "editable-gaussian-reflections_amd"
-GOLD = os.path.join(os.path.dirname(__file__), "golden")
-OUT_KEYS = ["output_rgb", "output_depth", "output_normal", "output_f0", "output_roughness", "output_transmittance",
-            "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final"]
-GRAD_KEYS = ["dL_drgb", "dL_dnormal", "dL_df0", "dL_droughness", "dL_dopacity", "dL_dscale", "dL_dmean", "dL_drotation", "total_weight"]
-
-
-@pytest.fixture(scope="module")
-def ren():
-    if not torch.cuda.is_available():
-        pytest.fail("-m gpu tests need a GPU; the product has no CPU fallback")
-    return importlib.import_module(PKG + ".renderer")
-
-
-def psnr(a, b):
-    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
-    return 150.0 if mse == 0 else 10.0 * np.log10(1.0 / mse)
-
-
-def make_pair(ren, orc, g, cam, W, H, cfg=None, fwd=8_000_000, bwd=8_000_000, **kw):
-    """Returns (GaussianRaytracer, Oracle) fed the same scene / camera / config."""
-    pc = ren.GaussianParams(g)
-    rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=fwd, ppll_backward_size=bwd, **kw)
-    o = orc.Oracle(W, H)
-    o.set_camera(cam["origin"], cam["c2w"], cam["fov"], cam.get("znear", 0.01), cam.get("zfar", 999.9))
-    o.set_gaussians(g)
-    c = dict(loss_weight_diffuse=5.0, loss_weight_specular=3.0, loss_weight_normal=2.5, loss_weight_depth=2.5, loss_weight_f0=1.0,
-             loss_weight_roughness=1.0)
-    c.update(cfg or {})
-    o.set_config(**c)
-    mc = rt.cuda_module.get_config()
-    for k, v in (cfg or {}).items():
-        getattr(mc, k).fill_(v)
-    o.update_bvh()
-    return rt, o
-
-
-def cam_obj(ren, cam, targets=None):
-    images = {}
-    if targets:
-        images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in targets.items()}
-    return ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **images)
-
-
-def hip_outputs(rt):
-    fb = rt.cuda_module.get_framebuffer()
-    return {k: getattr(fb, k).cpu().numpy() for k in OUT_KEYS}
-
-
-def hip_grads(rt):
-    g = rt.cuda_module.get_gaussians()
-    return {k: getattr(g, k).cpu().numpy() for k in GRAD_KEYS}
-
-
-def run_grad(ren, rt, camera):
-    rt.zero_grad()
-    rt.cuda_module.get_gaussians().total_weight.zero_()
-    ren.render(camera, rt)
-    torch.cuda.synchronize()
+from hip_common import GOLD, GRAD_KEYS, OUT_KEYS, cam_obj, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
 
 
 # ------------------------------------------------------------------------------------------------ K1/K2
@@ -121,10 +63,38 @@ def test_duplicate_positions_build_a_valid_tree(ren, orc, syn):
     assert psnr(hip_outputs(rt)["output_rgb"], ref["output_rgb"]) > 50  # 256 concentric Gaussians: near-tied depths
 
 
-def test_exact_depth_ties_are_composited_once_each(ren, orc, syn):
-    """Every gaussian exists twice (bit-identical copies): all depths tie pairwise and rays carry more than one batch of
-    hits, so the 8-way sorted insertion and the batch hand-over both meet equal keys. Each copy must be composited exactly once
-    (a copy taken twice shows up as T < T_total)."""
+def test_q3_tie_drop_at_16_hit_batch_boundaries_matches_oracle(ren, orc, syn):
+    """Quirk Q3 (forward_pass.cu:62): the reference selects hits 16 at a time with a strict `>` against the last composited
+    distance, so hits that tie with the 16th, 32nd, ... composited hit of their ray are DROPPED (how many is deterministic,
+    which ones is its list order). 20 bit-identical copies of every gaussian: all depths tie 20-fold, every ray composites the
+    first 16 copies of each surfel it meets and loses 4 - an order-independent known answer, and the oracle restates the rule."""
+    W, H = 48, 32
+    g = syn.make_scene(600, "init", seed=13)  # opacity 0.1: alpha <= 0.1, 16 hits leave T >= 0.18 > the threshold
+    g20 = {k: np.concatenate([v] * 20, 0) for k, v in g.items()}
+    cam = syn.default_camera()
+    # (threshold 0: no early stop in the middle of a batch, so every ray composites whole batches of 16 tied copies)
+    rt, o = make_pair(ren, orc, g20, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=0, transmittance_threshold=0.0))
+    with torch.no_grad():
+        rt(cam_obj(ren, cam))
+    ref = o.raytrace(False)
+    out = hip_outputs(rt)
+    ha = rt.cuda_module.get_stats().num_accumulated_per_pixel.cpu().numpy()
+    bad, nbad = mismatch_list(ha, ref["num_accumulated"])
+    report("q3_ties", mismatching_pixels=nbad, first=bad, max_hits=int(ha.max()),
+           psnr_rgb=round(psnr(out["output_rgb"][0], ref["output_rgb"][0]), 1))
+    assert nbad == 0, bad
+    assert int(ha.max()) >= 32 and np.all(ha % 16 == 0)  # whole batches of 16 ties, more than one batch somewhere
+    T, Tt = out["output_transmittance"][0], out["output_total_transmittance"][0]
+    assert bool((Tt < 0.9 * T).any())  # the dropped copies still count in T_total (shaders.cu:69-71)
+    for k in ("output_rgb", "output_transmittance", "output_total_transmittance", "output_depth", "output_final"):
+        assert psnr(out[k], ref[k]) > 100, k
+
+
+def test_exact_depth_ties_inside_a_batch_are_all_composited(ren, orc, syn):
+    """Two bit-identical copies of every gaussian: ties come in pairs, so no pair straddles a 16-hit batch boundary (hits are
+    taken in pairs from an even position) and nothing is dropped; both copies are composited exactly once (a copy taken
+    twice would show up as T < T_total). Rays carry several batches, so the 8-way sorted insertion and the batch hand-over
+    both meet equal keys."""
     W, H = 64, 48
     g = syn.make_scene(1500, "init", seed=13)  # opacity 0.1: long hit lists
     g2 = {k: np.concatenate([v, v], 0) for k, v in g.items()}
@@ -136,17 +106,21 @@ def test_exact_depth_ties_are_composited_once_each(ren, orc, syn):
     out = hip_outputs(rt)
     assert np.all(out["output_total_transmittance"] <= out["output_transmittance"] + 4e-6)
     st = rt.cuda_module.get_stats()
-    assert int(st.num_accumulated_per_pixel.max().item()) > 8  # more than one batch somewhere
+    assert int(st.num_accumulated_per_pixel.max().item()) > 16  # more than one reference batch somewhere
     for k in ("output_rgb", "output_transmittance", "output_total_transmittance", "output_final"):
         assert psnr(out[k], ref[k]) > 70, k
-    ha = st.num_accumulated_per_pixel.cpu().numpy().reshape(-1)
-    assert (ha != ref["num_accumulated"].reshape(-1)).mean() < 2e-3
+    ha = st.num_accumulated_per_pixel.cpu().numpy()
+    bad, nbad = mismatch_list(ha, ref["num_accumulated"])  # (last executed step: bounce rays differ by ulps between the two)
+    report("pair_ties", mismatching_pixels=nbad, of=W * H, first=bad)
+    assert nbad <= 6, bad
 
 
 # ------------------------------------------------------------------------------------------------ forward
 @pytest.mark.parametrize("variant", ["trained", "init"])
 def test_forward_strict_parity_primary(ren, orc, syn, variant):
-    """jitter off, num_bounces 0: the strict-parity configuration of SURVEY.md 8d."""
+    """jitter off, num_bounces 0: the strict-parity configuration of SURVEY.md 8d. Integer outputs are compared exactly; the
+    pixels that differ are listed (two implementations round a distance differently by an ulp and a grazing candidate flips
+    across a clip test - expf / the fma contraction differ between the CPU and the GPU), not tolerated by fraction."""
     W, H = 96, 64
     g = syn.make_scene(4000, variant, seed=11)
     cam = syn.default_camera()
@@ -157,26 +131,83 @@ def test_forward_strict_parity_primary(ren, orc, syn, variant):
     out = hip_outputs(rt)
     st = rt.cuda_module.get_stats()
     ht, ha = st.num_traversed_per_pixel.cpu().numpy(), st.num_accumulated_per_pixel.cpu().numpy()
+    bad_acc, n_acc = mismatch_list(ha, ref["num_accumulated"])
+    worst = {}
     for k in OUT_KEYS:
-        # Two hits whose depths differ by an ulp may composite in the other order (the distance is rounded differently by
-        # the two implementations): same hit count and transmittance, slightly different colour. Such pixels are rare
-        # (< 0.1 %) and must agree in everything order-independent; all others agree to 2e-4 absolute.
+        # Two hits whose depths differ by an ulp may composite in the other order: same hit count and transmittance, slightly
+        # different colour. Such pixels must agree in everything order-independent; all others agree to 2e-4 absolute.
         err = np.abs(out[k] - ref[k]).reshape(3, H * W, -1).max(-1)[0]
         swapped = err >= 2e-4
-        assert swapped.mean() < 1e-3, (k, int(swapped.sum()))
-        assert np.array_equal(ha.reshape(-1)[swapped], ref["num_accumulated"].reshape(-1)[swapped]), k
-        assert np.abs(out["output_transmittance"] - ref["output_transmittance"]).max() < 2e-6
+        worst[k] = (int(swapped.sum()), round(psnr(out[k], ref[k]), 1))
+        assert swapped.sum() <= 2, (k, int(swapped.sum()))
+        flip = ha.reshape(-1)[swapped] != ref["num_accumulated"].reshape(-1)[swapped]
+        assert flip.sum() <= n_acc, k
         assert err.max() < 1e-2, k
-        assert psnr(out[k], ref[k]) > 80, k
-    # num_traversed counts the intersection evaluations that passed the cube test. The oracle (like OptiX) looks at every
-    # gaussian whose CUBE the segment overlaps; the HIP tree bounds ellipsoids, so it evaluates a subset (every ACCEPTED
-    # candidate is in it - the images and num_accumulated prove that). One-ulp flips of grazing cube tests allowed.
-    assert (ht > ref["num_traversed"]).mean() < 1e-3 and ht.sum() > 0.5 * ref["num_traversed"].sum()
-    assert (ha != ref["num_accumulated"]).mean() < 1e-3
+        assert psnr(out[k], ref[k]) > 90, k
+    assert np.abs(out["output_transmittance"] - ref["output_transmittance"]).max() < 2e-6
+    report("strict_primary_" + variant, acc_mismatch=n_acc, acc_first=bad_acc, swapped_and_psnr=worst)
+    assert n_acc <= 1, bad_acc  # measured: 0 on both variants
+    # default launches count the EVALUATED subset of the reference's intersection invocations (include/egr_raytracer.h:
+    # egr_set_exact_stats); the exact count is compared in test_exact_stats_mode_counts_reference_invocations
+    assert (ht > ref["num_traversed"]).sum() <= 2 and ht.sum() > 0.5 * ref["num_traversed"].sum()
     seeds = rt.cuda_module.get_metadata().random_seeds.cpu().numpy().astype(np.uint32).reshape(H, W)
     assert np.array_equal(seeds, ref["random_seeds"].reshape(H, W))
     c = rt.cuda_module.get_counters()
     assert c[0] == W * H and c[1] == 0 and c[3] == int(ht.sum()) and c[11] == 0
+
+
+@pytest.mark.parametrize("variant,bounces", [("trained", 0), ("trained", 2), ("init", 2)])
+def test_exact_stats_mode_counts_reference_invocations(ren, orc, syn, variant, bounces):
+    """T7: with set_exact_stats(True) the tree bounds the instance cubes and num_traversed_per_pixel is the reference's
+    number - invocations of the intersection program, all steps (shaders.cu:33, forward_pass.cu:46) - equal to the oracle's
+    pixel by pixel (listed exceptions: a cube that a ray grazes within an ulp). Images do not depend on the mode."""
+    W, H = 96, 64
+    g = syn.make_scene(4000, variant, seed=11)
+    cam = syn.default_camera()
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=bounces))
+    m = rt.cuda_module
+    with torch.no_grad():
+        rt(cam_obj(ren, cam))
+    base = hip_outputs(rt)
+    sub = m.get_stats().num_traversed_per_pixel.cpu().numpy().copy()
+    m.set_exact_stats(True)
+    with pytest.raises(RuntimeError):  # the boxes are still ellipsoid boxes
+        with torch.no_grad():
+            rt(cam_obj(ren, cam))
+    m.get_metadata().total_num_calls.zero_()
+    with torch.no_grad():
+        rt(cam_obj(ren, cam), force_update_bvh=True)
+    assert m.check_bvh() == 0, m.last_error()
+    ref = o.raytrace(False)
+    out = hip_outputs(rt)
+    ht = m.get_stats().num_traversed_per_pixel.cpu().numpy()
+    bad, nbad = mismatch_list(ht, ref["num_traversed"])
+    c = m.get_counters()
+    report(f"exact_stats_{variant}_b{bounces}", mismatching_pixels=nbad, of=W * H, first=bad, hc_exact=int(ht.sum()), hc_oracle=int(ref["num_traversed"].sum()),
+           evaluated_default=int(sub.sum()))
+    if bounces == 0:
+        assert nbad <= 2, bad  # measured 0
+        assert abs(int(ht.sum()) - int(ref["num_traversed"].sum())) <= 2
+    else:  # bounce rays differ by ulps between the implementations: the counts of those steps agree statistically
+        assert nbad <= 0.02 * W * H, (nbad, bad)
+        assert abs(int(ht.sum()) - int(ref["num_traversed"].sum())) <= 2e-3 * int(ref["num_traversed"].sum())
+    assert c[3] + c[4] + c[5] == int(ht.sum()) and c[11] == 0
+    assert np.all(sub <= ht + 0) or (sub > ht).sum() <= 2  # the default count is a subset
+    for k in ("output_rgb", "output_depth", "output_normal", "output_transmittance", "output_total_transmittance", "output_final"):
+        if k != "output_final":
+            assert psnr(out[k][0], base[k][0]) > 110, k  # step 0: same accepted set, same order (T_total: another product order)
+        assert psnr(out[k], ref[k]) > (90 if bounces == 0 else 50), k
+    # gradients come out the same in both modes
+    tg = syn.make_targets(W, H)
+    m.get_metadata().total_num_calls.zero_()
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    ge = hip_grads(rt)
+    m.set_exact_stats(False)
+    m.get_metadata().total_num_calls.zero_()
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    gd = hip_grads(rt)
+    for k in GRAD_KEYS:
+        assert np.abs(ge[k] - gd[k]).max() / (np.abs(gd[k]).max() + 1e-30) < 1e-4, k
 
 
 def test_forward_parity_with_bounces_and_jitter(ren, orc, syn):
@@ -190,10 +221,17 @@ def test_forward_parity_with_bounces_and_jitter(ren, orc, syn):
         ref = o.raytrace(False)
         out = hip_outputs(rt)
         assert int(rt.cuda_module.get_metadata().total_num_calls.item()) == o.total_num_calls
+        levels = {}
         for k in ("output_rgb", "output_final", "output_normal", "output_depth"):
             for s in range(out[k].shape[0]):
-                assert psnr(out[k][s], ref[k][s]) > 50.0, (k, s, call)
-        assert psnr(out["output_rgb"][0], ref["output_rgb"][0]) > 90
+                levels[f"{k}[{s}]"] = round(psnr(out[k][s], ref[k][s]), 1)
+        report(f"bounces_jitter_call{call}", **levels)
+        # the north-star bar is 50 dB; the asserted levels are what is measured (step 0 differs by round-off; a bounce ray that
+        # differs by an ulp may meet another grazing candidate, which is what the lower levels of steps 1 and 2 are)
+        bars = {"output_rgb[0]": 120, "output_depth[0]": 115, "output_normal[0]": 80, "output_rgb[1]": 95, "output_depth[1]": 95, "output_normal[1]": 90,
+                "output_rgb[2]": 70, "output_depth[2]": 60, "output_normal[2]": 50, "output_final[0]": 70}
+        for k, v in levels.items():
+            assert v > bars[k], (k, v, call)
         assert (ref["effective_steps"] > 1).mean() > 0.5  # the bounce steps were really exercised
 
 
@@ -472,70 +510,6 @@ def test_strands_do_not_change_results(ren, orc, syn):
         m.set_strands(99)
 
 
-def test_quarter_tile_split_does_not_change_results(ren, orc, syn, monkeypatch):
-    """Bounce steps traced as quarter tiles (16 rays per wave, four arena chains per tile: what a rank with few tiles per
-    wave slot does, EGR_SPLIT) give bit-identical images and the same gradients as whole-tile tasks."""
-    W, H = 200, 136
-    g = syn.make_scene(20000, "trained", seed=4)
-    cam = syn.default_camera()
-    tg = syn.make_targets(W, H)
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("EGR_SPLIT", mode)
-        rt, _ = make_pair(ren, orc, g, cam, W, H, fwd=40_000_000, bwd=40_000_000)
-        m = rt.cuda_module
-        m.get_config().num_bounces.fill_(2)
-        with torch.no_grad():
-            rt(cam_obj(ren, cam))
-        img = hip_outputs(rt)
-        m.get_metadata().total_num_calls.zero_()
-        run_grad(ren, rt, cam_obj(ren, cam, tg))
-        c = m.get_counters()
-        assert c[11] == 0, "status"
-        res[mode] = (img, hip_grads(rt), list(c[:9]))
-        del rt
-    for k in OUT_KEYS:
-        assert np.array_equal(res["0"][0][k], res["1"][0][k]), k
-    assert res["0"][2] == res["1"][2]
-    assert res["0"][2][1] > 0 and res["0"][2][7] > 0  # bounce rays were traced and composited
-    for k in GRAD_KEYS:
-        assert np.abs(res["0"][1][k] - res["1"][1][k]).max() / (np.abs(res["0"][1][k]).max() + 1e-30) < 1e-4, k
-
-
-def test_fused_tile_chain_does_not_change_results(ren, orc, syn, monkeypatch):
-    """The fused per-tile forward chain (one wave takes a tile through all its steps, with the step epilogue inlined from the
-    contraction-free header; what a rank with few tiles per wave slot runs, EGR_CHAIN) gives bit-identical images, states and
-    counters as the step-by-step kernels, and the same gradients."""
-    W, H = 200, 136
-    g = syn.make_scene(20000, "trained", seed=4)
-    cam = syn.default_camera()
-    tg = syn.make_targets(W, H)
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("EGR_CHAIN", mode)
-        monkeypatch.setenv("EGR_SPLIT", "0")
-        rt, _ = make_pair(ren, orc, g, cam, W, H, fwd=40_000_000, bwd=40_000_000)
-        m = rt.cuda_module
-        m.get_config().num_bounces.fill_(2)
-        with torch.no_grad():
-            rt(cam_obj(ren, cam))
-        img = hip_outputs(rt)
-        seeds = m.get_metadata().random_seeds.cpu().numpy().copy()
-        m.get_metadata().total_num_calls.zero_()
-        run_grad(ren, rt, cam_obj(ren, cam, tg))
-        c = m.get_counters()
-        assert c[11] == 0, "status"
-        res[mode] = (img, hip_grads(rt), list(c[:9]), seeds)
-        del rt
-    for k in OUT_KEYS:
-        assert np.array_equal(res["0"][0][k], res["1"][0][k]), k
-    assert np.array_equal(res["0"][3], res["1"][3])
-    assert res["0"][2] == res["1"][2]
-    assert res["0"][2][1] > 0 and res["0"][2][7] > 0  # bounce rays were traced and composited
-    for k in GRAD_KEYS:
-        assert np.abs(res["0"][1][k] - res["1"][1][k]).max() / (np.abs(res["0"][1][k]).max() + 1e-30) < 1e-4, k
-
-
 # ------------------------------------------------------------------------------------------------ full size
 def test_full_size_properties_1080p_1M(ren, orc, syn):
     """BASELINE config C (1080p, 1M Gaussians): size-independent properties instead of a full oracle run."""
@@ -591,27 +565,3 @@ def test_full_size_properties_1080p_1M(ren, orc, syn):
     assert float((w1 - w2).abs().max()) <= 1e-3 * float(w1.abs().max())
     d1, d2 = g1[: n22 - N], g2[: n22 - N]
     assert float((d2 - 2 * d1).abs().max()) <= 2e-3 * float(d1.abs().max())
-
-
-def test_full_size_gradient_paths_agree(ren, orc, syn, monkeypatch):
-    """1080p / 1M: the bucketed bounce backward (LDS table -> wave-aggregated bucket appends -> counting-sort reduce -> gradient
-    rows -> gather) against plain global atomics on the gradient rows, same forward: only the summation order may differ."""
-    W, H, N = 1920, 1080, 1_000_000
-    g = syn.make_scene(N, "trained", seed=0)
-    cam = syn.default_camera()
-    tg = syn.make_targets(W, H)
-    grads = []
-    for bucketed in ("2", "1", "0", "3"):  # per-wave record logs, per-block buckets, plain atomics, records added directly (16 lanes each)
-        monkeypatch.setenv("EGR_BUCKETED_BACKWARD", bucketed)
-        rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000)
-        run_grad(ren, rt, cam_obj(ren, cam, tg))
-        c = rt.cuda_module.get_counters()
-        assert c[11] == 0 and (c[13] > 0) == (bucketed != "0")  # gradient records only on the record paths
-        grads.append(rt.cuda_module.get_gaussians().grad_flat.clone())
-        del rt
-        torch.cuda.empty_cache()
-    scale = float(grads[2].abs().max())
-    assert float((grads[0] - grads[2]).abs().max()) < 1e-5 * scale
-    assert float((grads[1] - grads[2]).abs().max()) < 1e-5 * scale
-    assert float((grads[3] - grads[2]).abs().max()) < 1e-5 * scale
-

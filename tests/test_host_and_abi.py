@@ -127,24 +127,31 @@ def run(r, w):
     o.set_gaussians(g); o.update_bvh(); o.set_partition(r, w)
     out = o.raytrace(True, targets=tg)
     return torch.cat([torch.from_numpy(out[k]).reshape(-1) for k, _ in par.GRAD_LAYOUT]), out
-flat, out = run(rank, world)              # this rank's tiles only
 own = par.owner_map(W, H, world)
-assert np.all(out["output_final"][0][own != rank] == 0)  # untouched pixels
-par.all_reduce_flat(flat)                 # the ONE exchange step
-full, _ = run(0, 1)
-err = float((flat - full).abs().max() / full.abs().max())
-views = par.split_flat(flat, N)
+full, _ = run(0, 1)                       # what a single process computes per launch
+persistent = torch.zeros_like(full)       # the raytracer's grad_flat: total_weight (the last N) lives across iterations
+for it in range(3):                       # three training iterations with a zero_grad in between (train.py:247-249)
+    delta, out = run(rank, world)         # this rank's tiles only -> the per-launch buffer (grad_delta)
+    assert np.all(out["output_final"][0][own != rank] == 0)  # untouched pixels
+    par.all_reduce_launch_delta(persistent, delta)   # the ONE exchange step, the product's own helper (renderer.all_reduce_grads)
+    assert float(delta.abs().max()) == 0.0           # emptied for the next launch
+    err = float((persistent[: 21 * N] - full[: 21 * N]).abs().max() / full.abs().max())
+    assert err < 1e-12, (it, err)
+    werr = float((persistent[21 * N:] - (it + 1) * full[21 * N:]).abs().max() / full[21 * N:].abs().max())
+    assert werr < 1e-12, (it, werr)       # total_weight = sum over iterations, NOT multiplied by the world size each time
+    persistent[: 21 * N].zero_()          # GaussianRaytracer.zero_grad keeps total_weight
+views = par.split_flat(persistent, N)
 assert views["dL_drotation"].shape == (N, 4) and views["total_weight"].shape == (N, 1)
-assert err < 1e-12, err
-if rank == 0: print("GLOO_OK", err)
+if rank == 0: print("GLOO_OK", err, werr)
 dist.destroy_process_group()
 """
 
 
 @pytest.mark.timeout(300)
 def test_two_rank_partition_plus_allreduce_equals_single_rank(tmp_path, orc):
-    """N>1 path on CPU: 2 processes (gloo), each runs its tile partition, one all-reduce of the flat [22N] buffer ->
-    bit-for-bit (fp64 oracle) the single-process gradients."""
+    """N>1 path on CPU: 2 processes (gloo), each runs its tile partition, then the product's exchange helper
+    (parallel.all_reduce_launch_delta: one all-reduce of the per-launch [22N] buffer, folded into the persistent one) over
+    three iterations -> bit-for-bit (fp64 oracle) the single-process gradients, and total_weight grows linearly."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
     env = dict(os.environ, OMP_NUM_THREADS="2")

@@ -7,7 +7,7 @@ set -u
 TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --strands 1 --steps 20 --warmup 50 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --strands 1 --steps 20 --warmup 50 --no-cpu-baseline --no-second-variant > $OUT/bench_under_rocprof.log 2>&1
 grep -a "^{" $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_REQ" "TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TOTAL_CACHE_ACCESSES" "TA_TA_BUSY TCP_GATE_EN1 TCP_PENDING_STALL_CYCLES"; do
