@@ -297,7 +297,13 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
 // Gradient pre-reduction (cdna guide, Guideline 12): the 64 primary rays of a tile composite the same few dozen Gaussians,
 // so per-hit contributions are first summed in a per-wave LDS hash table (ds_add_f32, open addressing on the
 // record index) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
-#define EGR_GT_SLOTS 128
+#ifndef EGR_GT_SLOTS
+#define EGR_GT_SLOTS 64 // slots of the primary step's LDS table (power of two, >= 64). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
+                        // per CU) and a hit that finds no slot leaves as wide adds anyway (trained 3.46 -> 3.25 ms, dense-init 7.7 -> 4.9 ms)
+#endif
+#ifndef EGR_PRIMARY_TABLE
+#define EGR_PRIMARY_TABLE 1 // 0 (measured: 4.8 instead of 3.3 ms): primary hits skip the LDS table and leave as records like bounce hits
+#endif
 #define EGR_GT_COMPS 22
 #define EGR_GT_EMPTY 0xFFFFFFFFu
 // component order of the LDS table, of a wide-add record (first 15) and of a gradient row (DeviceView::grad_rows)
@@ -357,7 +363,10 @@ EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_v
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
 // last bounce first (15 gradient components per hit, straight out as wide adds), then the primary step (22 components through
 // the LDS table). Per-step code: backward_task.inc.
-__global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) k_backward_chain(DeviceView v) {
+#ifndef EGR_BWD_WAVES
+#define EGR_BWD_WAVES 3
+#endif
+__global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(EGR_BWD_WAVES, EGR_BWD_WAVES))) k_backward_chain(DeviceView v) {
     const int lane = threadIdx.x;
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
     __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
@@ -508,7 +517,7 @@ void egr_build_task_order(egr_context *c) {
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
+    dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
     for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -534,10 +543,11 @@ void egr_trace_alloc(egr_context *c) {
     // forward budget: the reference's ppll_forward_size entries x 36 B, spent on (key 4 B + value 8 B) x 64 lanes x cap per slot
     double fwd_bytes = (double)c->fwd_capacity * 36.0;
     const size_t S = (size_t)c->strands; // every strand owns a full set of resident-wave scratch slots
-    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * (double)S * EGR_WAVE * 12.0)); // key 4 + value 8 bytes
+    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * (double)S * EGR_WAVE * 16.0)); // key 4 + value 8 + queue 4 bytes
     c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384) & ~7u;
     EGR_HIP(hipMalloc((void **)&c->cand_keys, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
     EGR_HIP(hipMalloc((void **)&c->cand_vals, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
+    EGR_HIP(hipMalloc((void **)&c->cand_queue, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
     // extension blocks: 1/8 of the forward byte budget on top (12 B per entry), at least 64 blocks
     c->ext_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(fwd_bytes / 8.0 / (12.0 * EGR_EXT_BLOCK)), 64), 65536);
     EGR_HIP(hipMalloc((void **)&c->ext_keys, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float)));
@@ -580,7 +590,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
-    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
+    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.ext_keys = c->ext_keys, v.ext_vals = c->ext_vals, v.ext_blocks_cap = c->ext_blocks_cap;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
@@ -617,7 +627,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             w.task_count = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)(st + 1)) / (uint64_t)S) - w.task_begin;
             w.queues = c->queues + EGR_QUEUE_WORDS * st;
             const size_t slot0 = (size_t)st * c->num_slots;
-            w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE;
+            w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE, w.cand_queue += slot0 * c->cand_cap * EGR_WAVE;
             w.stack_spill += slot0 * EGR_GSTK * EGR_WAVE;
             const dim3 sgrid(std::max(1u, std::min(c->num_slots, w.task_count)));
             egr_stamp_begin(c, "forward_chain", ls);
