@@ -200,7 +200,7 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
                 fprintf(stderr, "[egr stats forward step %d] first wave exit -> last wave exit: %.3f ms\n", k,
                         (double)(u64(CW_DBG3 + 4 * k + 2) - u64(CW_DBG3 + 4 * k)) / 100e6 * 1e3);
             for (int k = 0; k < 2; k++)
-                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | per-lane walk: phase A %llu phase B %llu\n", k ? "bounce" : "primary",
+                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | group walk: phase A %llu phase B %llu\n", k ? "bounce" : "primary",
                         (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2), (unsigned long long)u64(CW_DBG2 + 8 + 4 * k),
                         (unsigned long long)u64(CW_DBG2 + 8 + 4 * k + 2));
         }

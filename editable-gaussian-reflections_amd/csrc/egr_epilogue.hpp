@@ -1,13 +1,11 @@
 // Per-ray step epilogue = forward_pass.cu:142-155 (tail renormalisation, R4) + shaders.cu:111-147 (throughput,
 // GGX bounce sampling, next ray, R5). One lane per ray, once per bounce step.
 //
-// EVERYTHING IN THIS HEADER IS COMPILED WITH FMA CONTRACTION OFF (the pragma below; epilogue.hip additionally passes
-// -ffp-contract=off). sample_cook_torrance evaluates sin = sqrt(1 - cos*cos) with cos ~ 1 for near-mirror roughness; fusing
+// EVERYTHING IN THIS HEADER IS COMPILED WITH FMA CONTRACTION OFF (the pragma below). sample_cook_torrance evaluates sin = sqrt(1 - cos*cos) with cos ~ 1 for near-mirror roughness; fusing
 // that product into an fma changes the sampled direction by ~1e-4, which then decides which Gaussians the bounce ray
 // meets. Evaluating the handful of per-ray operations unfused (plain IEEE mul/add, what the source text says) keeps the
 // bounce rays bit-comparable with the CPU oracle. The vector type is a distinct one (f3u) so that its operators are the
-// contraction-free instantiation of egr_vec.inc, whichever translation unit includes this (k_step_epilogue in
-// epilogue.hip; the fused per-tile chain in trace.hip). It costs ~100 extra instructions per ray-step; the per-candidate
+// contraction-free instantiation of egr_vec.inc inside the fused per-tile chain of trace.hip. It costs ~100 extra instructions per ray-step; the per-candidate
 // hot loops keep contraction.
 #pragma once
 #include "egr_state.hpp"

@@ -76,7 +76,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     // per-launch scratch
     float *cand_keys;      // [slots][cand_cap][64]
     float2 *cand_vals;     // [slots][cand_cap][64]  (alpha, gaussian id bits)
-    uint32_t *cand_queue;  // [slots][cand_cap][64]  leaf record indices awaiting evaluation (per-lane walk)
+    uint32_t *cand_queue;  // [slots][cand_cap][64]  leaf record indices awaiting evaluation (group walk: phase A fills, phase B drains)
     uint32_t *stack_spill; // [slots][EGR_GSTK][64] traversal stack entries beyond the LDS part
     uint32_t cand_cap;
     // candidate lists longer than cand_cap continue in an extension block (one per ray, EGR_EXT_BLOCK entries, bump-allocated per

@@ -1,4 +1,4 @@
-// Per-ray state layout + task geometry shared by trace.hip (fused arithmetic) and epilogue.hip (unfused).
+// Per-ray state layout + task geometry (trace.hip; the step epilogue in egr_epilogue.hpp is the contraction-free part).
 #pragma once
 #include "egr_device.hpp"
 #include "egr_internal.hpp"
