@@ -306,3 +306,34 @@ def test_render_then_fused_step_counts_raytracer_gradients_once(ren, syn):
     assert step.exp_avg["xyz"].shape[0] == int(keep.sum())
     step.extend(10)
     assert step.exp_avg_sq["rotation"].shape == (int(keep.sum()) + 10, 4) and float(step.exp_avg["xyz"][-10:].abs().max()) == 0.0
+
+
+def test_resize_keeps_gradient_rows_and_total_weight(ren, syn):
+    """core/gaussians.h:64-86 resizes every tensor in place (`resize_`): the first min(old, new) rows of the gradient tensors and of
+    total_weight survive (train.py adds far-field points in the middle of a pruning interval without clearing total_weight); the
+    growth is zeroed here (uninitialised upstream). `.grad` of every parameter still aliases its dL_d* tensor."""
+    W, H = 48, 32
+    g = syn.make_scene(1200, "trained", seed=8)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=8_000_000, ppll_backward_size=8_000_000)
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    m = rt.cuda_module
+    before = {k: getattr(m.get_gaussians(), k).clone() for k in GRAD_KEYS}
+    assert float(before["total_weight"].abs().max()) > 0 and float(before["dL_dmean"].abs().max()) > 0
+    m.resize(1500)
+    gs = m.get_gaussians()
+    for k in GRAD_KEYS:
+        t = getattr(gs, k)
+        assert t.shape[0] == 1500 and torch.equal(t[:1200], before[k]) and float(t[1200:].abs().max()) == 0.0, k
+    assert gs.mean.grad.data_ptr() == gs.dL_dmean.data_ptr() and gs.rotation.grad.data_ptr() == gs.dL_drotation.data_ptr()
+    m.resize(700)
+    gs = m.get_gaussians()
+    for k in GRAD_KEYS:
+        assert torch.equal(getattr(gs, k), before[k][:700]), k
+    # the resized tracer still works: new values in, rebuild, grad launch
+    g2 = syn.make_scene(700, "trained", seed=9)
+    rt.pc.__init__(g2)
+    rt.rebuild_bvh()
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    assert m.get_counters()[11] == 0 and bool(torch.isfinite(m.get_gaussians().grad_flat).all())
