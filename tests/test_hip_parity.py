@@ -564,3 +564,39 @@ def test_full_size_properties_1080p_1M(ren, orc, syn):
     assert float((w1 - w2).abs().max()) <= 1e-3 * float(w1.abs().max())
     d1, d2 = g1[: n22 - N], g2[: n22 - N]
     assert float((d2 - 2 * d1).abs().max()) <= 2e-3 * float(d1.abs().max())
+
+
+def test_composited_hits_are_capped_at_99_batches_of_16(ren, orc, syn):
+    """forward_pass.cu:55 runs at most MAX_ITERATIONS = 99 selection rounds of BUFFER_SIZE = 16 hits (flags.h:15-16): a ray composites at
+    most 1584 hits per step, everything behind them only counts in T_total. 2500 nearly transparent gaussians in a row along the
+    view axis (distinct depths, threshold 0 so that nothing stops the ray earlier)."""
+    W = H = 8
+    n = 2500
+    g = {"mean": np.stack([2.0 + 0.01 * np.arange(n), np.zeros(n), np.zeros(n)], 1), "scale": np.full((n, 3), np.log(1.5)),
+         "rotation": np.tile(np.array([1.0, 0, 0, 0]), (n, 1)), "opacity": np.full((n, 1), np.log(0.01 / 0.99)),
+         "rgb": np.random.default_rng(0).uniform(0.1, 0.9, (n, 3)), "normal": np.tile(np.array([-1.0, 0, 0]), (n, 1)),
+         "f0": np.full((n, 3), 0.04), "roughness": np.full((n, 1), 0.3)}
+    g = {k: np.ascontiguousarray(v.astype(np.float32)) for k, v in g.items()}
+    cam = syn.plus_x_camera()
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=0, transmittance_threshold=0.0), fwd=20_000_000, bwd=20_000_000)
+    with torch.no_grad():
+        rt(cam_obj(ren, cam))
+    ref = o.raytrace(False)
+    out = hip_outputs(rt)
+    ha = rt.cuda_module.get_stats().num_accumulated_per_pixel.cpu().numpy()
+    assert int(ref["num_accumulated"].max()) == 1584 and int(ha.max()) == 1584
+    bad, nbad = mismatch_list(ha, ref["num_accumulated"])
+    report("hit_cap", mismatching_pixels=nbad, first=bad, capped_pixels=int((ha == 1584).sum()))
+    assert nbad == 0, bad
+    capped = (ha == 1584)
+    assert bool(np.all(out["output_total_transmittance"][0][capped] < out["output_transmittance"][0][capped]))  # the rest is in T_total only
+    for k in ("output_rgb", "output_depth", "output_transmittance", "output_total_transmittance"):
+        assert psnr(out[k], ref[k]) > 100, k
+    # gradients of the capped rays: the arena holds 198 blocks of 8 hits per tile
+    tg = syn.make_targets(W, H)
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    refg = o.raytrace(True, targets=tg)
+    gr = hip_grads(rt)
+    for k in GRAD_KEYS:
+        assert np.abs(gr[k] - refg[k]).max() / (np.abs(refg[k]).max() + 1e-30) < 1e-3, k
+    assert rt.cuda_module.get_counters()[11] == 0
