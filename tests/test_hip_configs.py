@@ -374,3 +374,58 @@ def test_every_config_scalar_is_read_on_the_device(ren, orc, syn, cfg):
     for k in GRAD_KEYS:  # a tensor the configuration switches off stays exactly zero on both sides
         if np.abs(refg[k]).max() == 0:
             assert float(np.abs(gr[k]).max()) == 0.0, k
+
+
+def test_reference_smoke_test_runs_unchanged():
+    """/root/reference/tests/test_gaussian_tracing.py:4-20, line for line against this build's libraytracer.so (the only test the
+    reference has for the path): construct at 1536x1024 with 300M / 200M list entries, set znear / zfar, set_pose with CPU tensors.
+    Then what the reference leaves out: shape errors surface as RuntimeError (camera.h:63-64) and the one zero-initialised instance
+    the constructor built a tree over (bvh_wrapper.h:17-22) can be traced."""
+    pkg = importlib.import_module(PKG)
+    torch.classes.load_library(pkg.GAUSS_TRACER_PATH)
+    raytracer = torch.classes.raytracer.Raytracer(1536, 1024, 1, 300_000_000, 200_000_000)
+    rot = torch.eye(3)
+    pos = torch.ones(3)
+    camera = raytracer.get_camera()
+    camera.znear.fill_(0.0001)
+    camera.zfar.fill_(100.0)
+    camera.set_pose(pos, rot)
+    with pytest.raises(RuntimeError):
+        camera.set_pose(torch.ones(4), rot)
+    with pytest.raises(RuntimeError):
+        camera.set_pose(pos, torch.eye(4))
+    assert raytracer.get_gaussians().mean.shape == (1, 3) and raytracer.get_gaussians().mean.grad is not None
+    with torch.no_grad():
+        raytracer.raytrace()
+    torch.cuda.synchronize()
+    fb = raytracer.get_framebuffer()
+    assert fb.output_rgb.shape == (3, 1024, 1536, 3) and fb.output_final.shape == (1, 1024, 1536, 3)
+    assert raytracer.get_counters()[11] == 0 and bool(torch.isfinite(fb.output_final).all())
+    assert float(fb.output_transmittance[0].min()) == 1.0  # opacity_raw = 0 -> sigmoid 0.5, scale exp(0) = 1 at the origin, camera at (1,1,1) looking along -z: nothing hit
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_arbitrary_cameras(ren, orc, syn, seed):
+    """Random camera rotation, position inside the room, field of view and aspect ratio: primary rays (T4) and everything behind them."""
+    rng = np.random.default_rng(seed)
+    W, H = [(72, 40), (40, 72), (56, 56)][seed]
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    cam = dict(origin=rng.uniform(-1.0, 1.0, 3).astype(np.float32), c2w=q.astype(np.float32), fov=np.float32(rng.uniform(0.3, 1.4)), znear=np.float32(0.01), zfar=np.float32(999.9))
+    g = syn.make_scene(3000, "trained", seed=50 + seed)
+    tg = generic_targets(syn, W, H)
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=1))
+    with torch.no_grad():
+        rt(cam_obj(ren, cam))
+    ref = o.raytrace(False)
+    out = hip_outputs(rt)
+    lv = {k: round(psnr(out[k], ref[k]), 1) for k in ("output_rgb", "output_final", "output_depth", "output_normal", "output_ray_direction")}
+    report(f"camera_{seed}", **lv)
+    assert min(lv.values()) > 70, lv
+    assert psnr(out["output_rgb"][0], ref["output_rgb"][0]) > 110
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    refg = o.raytrace(True, targets=tg)
+    gr = hip_grads(rt)
+    for k in GRAD_KEYS:
+        assert np.abs(gr[k] - refg[k]).max() / (np.abs(refg[k]).max() + 1e-30) < 2e-3, k
