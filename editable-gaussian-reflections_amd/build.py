@@ -24,6 +24,8 @@ if os.environ.get("EGR_GPOP"):
 for _k in ("EGR_FWD_WAVES", "EGR_PRIMARY_TABLE", "EGR_BWD_WAVES", "EGR_GT_SLOTS"):  # tuning experiments (tools/sweep.sh)
     if os.environ.get(_k):
         HIP_FLAGS.append("-D" + _k + "=" + os.environ[_k])
+if os.environ.get("EGR_EXTRA_FLAGS"):  # compiler-flag experiments, e.g. "-mllvm -amdgpu-sched-strategy=iterative-minreg"
+    HIP_FLAGS += os.environ["EGR_EXTRA_FLAGS"].replace(",", " ").split()
 if os.environ.get("EGR_TASK_TIMES"):  # diagnostic: per-task walk / composite time of one step in the stats images (tools/task_times.py)
     HIP_FLAGS.append("-DEGR_TASK_TIMES=" + os.environ["EGR_TASK_TIMES"])
 if os.environ.get("EGR_DEBUG_PIXEL"):
