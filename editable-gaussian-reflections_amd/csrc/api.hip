@@ -8,6 +8,7 @@
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s);
 void egr_denoise_atrous(egr_context *c, hipStream_t s); // denoise.hip
+void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s); // trace.hip
 
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s) {
     if (!c->timing) return;
@@ -108,10 +109,7 @@ int egr_set_gaussians(egr_context *c, const egr_gaussians *g) {
 int egr_set_partition(egr_context *c, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return 1;
     c->rank = rank, c->world = world;
-    return guarded(c, [&] {
-        EGR_HIP(hipDeviceSynchronize());
-        egr_build_task_order(c);
-    });
+    return guarded(c, [&] { egr_build_task_order(c); }); // cached per (rank, world): flipping between two partitions costs nothing
 }
 
 int egr_set_exact_stats(egr_context *c, int enable) {
@@ -267,6 +265,11 @@ int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, voi
         if (W) unpermute(c->inst_w, W, 16);
         if (aabb) EGR_HIP(hipMemcpy(aabb, c->aabb, n * 6 * sizeof(float), hipMemcpyDeviceToHost));
     });
+}
+
+int egr_debug_get_step_hits(egr_context *c, int32_t *host_out, void *stream) {
+    if (!c || !host_out) return 1;
+    return guarded(c, [&] { egr_export_step_hits(c, host_out, (hipStream_t)stream); });
 }
 
 int egr_debug_check_bvh(egr_context *c, void *stream) {

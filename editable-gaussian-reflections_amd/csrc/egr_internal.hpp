@@ -37,7 +37,10 @@ inline void egr_hip_check(hipError_t e, const char *what) {
 // ---- per-Gaussian records (internal layout in HBM) -----------------------------------------------------
 // inst_w : float4[4N]   64-B test record: rows of W = M^-1 (world->object; snapshot at update/rebuild) + live
 //                       quarter (f0.z, roughness, opacity, sigma) written per launch: one candidate test = one 64-B sector
-// inst_m : float4[4N]   64-B backward record: rows of M (object->world) with exp(scale) in .w, raw quaternion; snapshot
+// inst_m : float4[4N]   64-B backward record: rows 0-2 = (row of M (object->world; snapshot), exp(scale_a)), row 3 = raw quaternion;
+//                       exp(scale) and the quaternion are LIVE: k_live rewrites them in every grad launch (backward_pass.cu:68-70
+//                       reads them from the parameter tensors), so between an update and the next grad launch the record mixes
+//                       snapshot M rows with the scale / rotation of the last grad launch
 // grad_rows: float[32N] gradient accumulation, one 128-B line per gaussian (22 components used), zero between launches
 // app    : float4[2N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y)       32 B
 // wnodes : uint4[8*Nw]     8-wide BVH, one 128-B line per node; child slot (16 B):
@@ -69,10 +72,10 @@ struct DeviceView { // everything a kernel needs, passed by value
     const uint32_t *pos_of_gid; // [n] inverse
     BvhFrame frame;
     const uint32_t *out_of_frame; // != 0: some box carries the -inf / +inf sentinel cells (see qslab_hit)
-    const float4 *inst_w;
-    const float4 *inst_m;       // [n][4] backward record: rows 0-2 = (M row, exp(scale_a)), row 3 = raw quaternion
+    float4 *inst_w;             // [n][4] test record: rows 0-2 = W (snapshot), row 3 = live quarter (k_live writes it per launch)
+    float4 *inst_m;             // [n][4] backward record: rows 0-2 = (M row (snapshot), exp(scale_a) (live)), row 3 = raw quaternion (live)
     float *grad_rows;           // [n][32] gradient accumulation rows in record order (one 128-B line per gaussian)
-    const float4 *app;
+    float4 *app;                // [n][2] live appearance (k_live writes it per launch)
     // per-launch scratch
     float *cand_keys;      // [slots][cand_cap][64]
     float2 *cand_vals;     // [slots][cand_cap][64]  (alpha, gaussian id bits)
@@ -178,7 +181,12 @@ struct egr_context {
     float *state = nullptr;
     uint32_t state_stride = 0;
     uint32_t num_tasks_total = 0; // wave tiles in the whole image
-    uint32_t *task_macro = nullptr; // device table, rebuilt by egr_build_task_order when the partition changes
+    uint32_t *task_macro = nullptr; // device table of the current partition's tile order: one of task_orders[].table
+    struct TaskOrder {              // tile orders built so far (a partitioned trainer flips between (rank, world) for training launches and
+        int rank, world;            // (0, 1) for evaluation renders: egr_set_partition then only swaps a pointer, no sync, no upload)
+        uint32_t *table;
+    };
+    std::vector<TaskOrder> task_orders;
     uint32_t *control = nullptr;
     uint32_t *control_host = nullptr; // pinned
     // timing

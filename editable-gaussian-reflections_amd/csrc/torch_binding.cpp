@@ -422,6 +422,11 @@ struct Raytracer : torch::CustomClassHolder {
         for (int i = 0; i < n; i++) out.emplace_back(std::string(names[i]), (double)ms[i]);
         return out;
     }
+    Tensor debug_step_hits() { // [3,H,W] int32 on the host: composited hits per bounce step of the last grad launch
+        Tensor t = torch::zeros({EGR_NUM_STEPS, height, width}, torch::kInt32);
+        check(egr_debug_get_step_hits(ctx, t.data_ptr<int32_t>(), current_stream()), "debug_step_hits");
+        return t;
+    }
     int64_t check_bvh() { return egr_debug_check_bvh(ctx, current_stream()); }
     std::string last_error() { return egr_last_error(ctx); }
     std::vector<Tensor> debug_instances() {
@@ -494,7 +499,8 @@ struct Raytracer : torch::CustomClassHolder {
             .def("last_kernel_ms", &Raytracer::last_kernel_ms)
             .def("check_bvh", &Raytracer::check_bvh)
             .def("last_error", &Raytracer::last_error)
-            .def("debug_instances", &Raytracer::debug_instances);
+            .def("debug_instances", &Raytracer::debug_instances)
+            .def("debug_step_hits", &Raytracer::debug_step_hits);
     }
 };
 
@@ -520,6 +526,7 @@ static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch
     TORCH_CHECK(grads.size() == G && rt_params.size() == G && rt_grads.size() == G && exp_avg.size() == G && exp_avg_sq.size() == G && lrs.size() == G &&
                     clamp_min.size() == G && clamp_max.size() == G && log_decay.size() == G,
                 "fused_adam_step: all lists need one entry per group");
+    TORCH_CHECK(group_steps.empty() || group_steps.size() == G, "fused_adam_step: group_steps must be empty (every group uses `step`) or hold one count per group");
     egr_param_group g[EGR_MAX_PARAM_GROUPS];
     const int64_t n = params[0].size(0);
     auto ptr = [&](const torch::Tensor &t, const torch::Tensor &like, const char *what) -> float * {
@@ -546,7 +553,7 @@ static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch
 TORCH_LIBRARY(simple_knn, m) { m.def("distCUDA2(Tensor points) -> Tensor", &dist_hip2); }
 TORCH_LIBRARY(egr, m) {
     m.def("fused_adam_step(Tensor[] params, Tensor[] grads, Tensor[] rt_params, Tensor[] rt_grads, Tensor[] exp_avg, Tensor[] exp_avg_sq, float[] lrs, "
-          "float[] clamp_min, float[] clamp_max, float[] log_decay, int step, float beta1, float beta2, float eps, int[] group_steps) -> ()",
+          "float[] clamp_min, float[] clamp_max, float[] log_decay, int step, float beta1, float beta2, float eps, int[] group_steps=[]) -> ()",
           &fused_adam_step);
 }
 

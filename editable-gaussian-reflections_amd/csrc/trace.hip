@@ -15,7 +15,8 @@
 //     is replaced by a per-resident-wave candidate scratch, one contiguous run per lane ([lane][k]) with bump-allocated
 //     extension blocks for the rare long list; it is reused tile after tile;
 //   * depth ordering = strict-successor selection in batches of 8 (sorted insertion in registers, stable on ties);
-//     semantically the reference's 16-at-a-time k-buffer (forward_pass.cu:55-137) without its batch-boundary tie drop;
+//     semantically the reference's 16-at-a-time k-buffer (forward_pass.cu:55-137) INCLUDING its batch-boundary tie drop (Q3: the tie
+//     continuation is switched off at every second batch boundary, forward_task.inc);
 //   * composited hits needed by the backward pass go to an arena in 8-row blocks (one atomic per 8 rows per WAVE instead
 //     of one per hit per lane), chained newest->oldest, which is the order backward walks;
 //   * backward recomputes the local hit point from the snapshot transform instead of storing it. Primary tiles sum their
@@ -240,13 +241,13 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
     float o = sigmoid_act(g.opacity[i]);
     float sigma = compute_scaling_factor(o, *v.cfg.alpha_threshold, *v.cfg.exp_power);
     const size_t pos = v.pos_of_gid[i]; // stored at the sorted position
-    float4 *app = const_cast<float4 *>(v.app) + 2 * pos;
+    float4 *app = v.app + 2 * pos;
     app[0] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
     app[1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
     // the 4th quarter of the 64-B test record (rows of W are the first three): what a candidate test needs besides W
-    const_cast<float4 *>(v.inst_w)[4 * pos + 3] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
+    v.inst_w[4 * pos + 3] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), o, sigma);
     if (grads) {
-        float4 *im = const_cast<float4 *>(v.inst_m) + 4 * pos;
+        float4 *im = v.inst_m + 4 * pos;
         im[0].w = expf(g.scale[3 * i]), im[1].w = expf(g.scale[3 * i + 1]), im[2].w = expf(g.scale[3 * i + 2]);
         im[3] = reinterpret_cast<const float4 *>(g.rotation)[i];
     }
@@ -475,6 +476,19 @@ __global__ void __launch_bounds__(EGR_WAVE) k_finish(DeviceView v) {
     }
 }
 
+// Diagnostic export (egr_debug_get_step_hits): composited hits per pixel and bounce step of the last GRAD launch, from the ray state
+// the backward chain reads (S_NHITS); steps a ray did not execute report 0. Pixels outside this rank's partition are not written.
+__global__ void __launch_bounds__(EGR_WAVE) k_export_step_hits(DeviceView v, int32_t *__restrict__ out) {
+    const int lane = threadIdx.x;
+    for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
+        const TaskGeom tg = task_geom(v, task, lane);
+        if (!tg.inside) continue;
+        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
+        const uint32_t steps = f2u(S.ld(F_STEPS));
+        for (int s = 0; s < EGR_NSTEPS; s++) out[(size_t)s * v.num_pixels + tg.pixel_id] = (uint32_t)s < steps ? (int32_t)f2u(S.ld(SF(s, S_NHITS))) : 0;
+    }
+}
+
 __global__ void k_copy3(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -497,6 +511,16 @@ uint32_t egr_num_tasks_for_rank(const egr_context *c) {
 // Order of this rank's macro tiles: sort by (XCD chunk block, Z-curve inside the block). The 8 chunks that
 // wave_next_task hands to the 8 XCD queues are equal slices of this order, so each is a compact image block.
 void egr_build_task_order(egr_context *c) {
+    for (const auto &o : c->task_orders)
+        if (o.rank == c->rank && o.world == c->world) { // built before: kernels in flight keep reading the table they were launched with
+            c->task_macro = o.table;
+            return;
+        }
+    if (c->task_orders.size() >= 8) { // a caller cycling through many partitions: drop the cache (nothing may still read the tables)
+        EGR_HIP(hipDeviceSynchronize());
+        for (auto &o : c->task_orders) (void)hipFree(o.table);
+        c->task_orders.clear();
+    }
     const uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
     auto part1by1 = [](uint32_t x) {
         x &= 0xFFFFu;
@@ -513,11 +537,17 @@ void egr_build_task_order(egr_context *c) {
     std::sort(keyed.begin(), keyed.end());
     std::vector<uint32_t> order(std::max<size_t>(keyed.size(), 1), 0u);
     for (size_t i = 0; i < keyed.size(); i++) order[i] = keyed[i].second;
-    EGR_HIP(hipMemcpy(c->task_macro, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    uint32_t *table = nullptr;
+    EGR_HIP(hipMalloc((void **)&table, order.size() * sizeof(uint32_t)));
+    EGR_HIP(hipMemcpy(table, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); // pageable source: returns after the copy
+    c->task_orders.push_back({c->rank, c->world, table});
+    c->task_macro = table;
 }
 
 void egr_trace_free(egr_context *c) {
-    dfree(c->stack_spill), dfree(c->task_macro), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
+    for (auto &o : c->task_orders) (void)hipFree(o.table);
+    c->task_orders.clear(), c->task_macro = nullptr;
+    dfree(c->stack_spill), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
     for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -573,7 +603,6 @@ void egr_trace_alloc(egr_context *c) {
             EGR_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
         }
     }
-    EGR_HIP(hipMalloc((void **)&c->task_macro, std::max<size_t>(c->num_tasks_total / 4, 1) * sizeof(uint32_t)));
     egr_build_task_order(c);
 }
 
@@ -660,6 +689,18 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
         }
     }
     hipLaunchKernelGGL(k_epilogue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
+}
+
+void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s) {
+    DeviceView v = egr_make_view(c);
+    const size_t bytes = (size_t)EGR_NSTEPS * v.num_pixels * sizeof(int32_t);
+    int32_t *dev = nullptr;
+    EGR_HIP(hipMalloc((void **)&dev, bytes));
+    EGR_HIP(hipMemsetAsync(dev, 0, bytes, s));
+    if (v.num_tasks) hipLaunchKernelGGL(k_export_step_hits, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev);
+    EGR_HIP(hipMemcpyAsync(host_out, dev, bytes, hipMemcpyDeviceToHost, s));
+    EGR_HIP(hipStreamSynchronize(s));
+    EGR_HIP(hipFree(dev));
 }
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s) {

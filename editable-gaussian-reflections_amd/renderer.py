@@ -119,7 +119,8 @@ class GaussianRaytracer:
 
     def _set_full_image(self, full):
         """No-grad renders produce images: a partitioned tracer then traces the WHOLE image on every rank (each rank would
-        otherwise only write the pixels of its own tiles and hand back stale data for the rest)."""
+        otherwise only write the pixels of its own tiles and hand back stale data for the rest). The library caches the tile order
+        of every partition it has seen, so the flip is a pointer swap: no device sync, no upload."""
         if self.world_size > 1:
             self.cuda_module.set_partition(0 if full else self.rank, 1 if full else self.world_size)
 
@@ -154,9 +155,11 @@ class GaussianRaytracer:
             self.cuda_module.update_bvh()
         if not grads:
             self._set_full_image(True)
-        self.cuda_module.raytrace()
-        if not grads:
-            self._set_full_image(False)
+        try:
+            self.cuda_module.raytrace()
+        finally:  # a raytrace that raises (stale BVH, exact-stats gate) must not leave a training rank tracing the whole image
+            if not grads:
+                self._set_full_image(False)
         if denoise:
             self.cuda_module.denoise()
         if grads:

@@ -10,7 +10,6 @@ utils/general_utils.py:31-60 (pinned by tests/golden/expon_lr.npz, generated fro
 import importlib
 import math
 
-import numpy as np
 import torch
 
 importlib.import_module(__package__).load_library()
@@ -22,15 +21,17 @@ CLAMPS = {"f_dc": (0.0, math.inf), "roughness": (0.0, 1.0), "f0": (0.0, 1.0)}  #
 
 
 def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
-    """utils/general_utils.py:31-60 (get_expon_lr_func's helper): log-linear interpolation with an optional delayed start."""
+    """The xyz learning-rate schedule (behaviour of utils/general_utils.py:31-60, pinned by tests/golden/expon_lr.npz):
+    geometric interpolation lr_init -> lr_final over max_steps, times a warm-up factor that eases from lr_delay_mult to 1
+    along a quarter sine over the first lr_delay_steps. A negative step or two zero rates switch the group off."""
     if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
         return 0.0
+    frac = min(max(step / max_steps, 0.0), 1.0)
+    rate = lr_init * (lr_final / lr_init) ** frac  # = exp((1 - frac) ln lr_init + frac ln lr_final)
     if lr_delay_steps > 0:
-        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-    else:
-        delay_rate = 1.0
-    t = np.clip(step / max_steps, 0, 1)
-    return float(delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+        ease = math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        rate *= lr_delay_mult + (1.0 - lr_delay_mult) * ease
+    return float(rate)
 
 
 class FusedTrainStep:
@@ -46,7 +47,6 @@ class FusedTrainStep:
         self.beta1, self.beta2, self.eps, self.scale_decay = beta1, beta2, eps, scale_decay
         self.xyz_schedule = xyz_schedule
         self.steps = 0
-        self.group_steps = {name: 0 for name, _, _ in GROUPS}  # torch.optim.Adam keeps one step count per parameter tensor
         self.exp_avg = {name: torch.zeros_like(getattr(pc, attr)) for name, attr, _ in GROUPS}
         self.exp_avg_sq = {name: torch.zeros_like(getattr(pc, attr)) for name, attr, _ in GROUPS}
         # the fused kernel adds the raytracer-side gradients itself: GaussianRaytracer.__call__ must not import them as well
@@ -72,11 +72,13 @@ class FusedTrainStep:
 
     @torch.no_grad()
     def reset_state(self, name):
-        """gaussian_model.py `replace_tensor_to_optimizer`: zero moments of one group (its parameter was replaced)."""
+        """gaussian_model.py:464-476 `replace_tensor_to_optimizer`: the group's parameter was replaced, both moments restart at zero.
+        The stored state object - and with it torch's `step` count, hence the bias correction - is re-attached unchanged, so the
+        first update after a reset is lr * m_hat / sqrt(v_hat) with the OLD step count (about 3.16 lr sign(g) late in training,
+        not lr sign(g))."""
         attr = {n: a for n, a, _ in GROUPS}[name]
         self.exp_avg[name] = torch.zeros_like(getattr(self.pc, attr))
         self.exp_avg_sq[name] = torch.zeros_like(getattr(self.pc, attr))
-        self.group_steps[name] = 0
 
     def update_learning_rate(self, iteration):  # gaussian_model.py:349-355
         if self.xyz_schedule is not None:
@@ -86,9 +88,7 @@ class FusedTrainStep:
     @torch.no_grad()
     def step(self):
         g = self.rt.cuda_module.get_gaussians()
-        self.steps += 1
-        for name in self.group_steps:
-            self.group_steps[name] += 1
+        self.steps += 1  # one count for all groups: none of the reference's optimizer surgery touches torch's per-tensor `step`
         params = [getattr(self.pc, attr) for _, attr, _ in GROUPS]
         grads = [getattr(self.pc, attr).grad for _, attr, _ in GROUPS]
         rt_params = [getattr(g, rt) for _, _, rt in GROUPS]
@@ -97,4 +97,4 @@ class FusedTrainStep:
             params, grads, rt_params, rt_grads, [self.exp_avg[n] for n, _, _ in GROUPS], [self.exp_avg_sq[n] for n, _, _ in GROUPS],
             [self.lrs[n] for n, _, _ in GROUPS], [CLAMPS.get(n, (-math.inf, math.inf))[0] for n, _, _ in GROUPS],
             [CLAMPS.get(n, (-math.inf, math.inf))[1] for n, _, _ in GROUPS], [self.scale_decay if n == "scaling" else 1.0 for n, _, _ in GROUPS],
-            self.steps, self.beta1, self.beta2, self.eps, [self.group_steps[n] for n, _, _ in GROUPS])
+            self.steps, self.beta1, self.beta2, self.eps)

@@ -180,6 +180,11 @@ int egr_last_kernel_ms(egr_context *ctx, float *ms, const char **names, int max_
 /* Copies the snapshot instance records for parity tests: M[N*12], W[N*12] (3x4 row-major), aabb[N*6]
  * (lo xyz, hi xyz; invisible instances have lo > hi). Host pointers; synchronises. */
 int egr_debug_get_instances(egr_context *ctx, float *M, float *W, float *aabb, void *hip_stream);
+/* Composited hits per pixel and bounce step of the last egr_raytrace with grads_enabled (what backward_pass.cu:38-45 calls
+ * num_hits[step]; the reference keeps it in registers, stats.num_accumulated_per_pixel only shows the last step): host_out =
+ * int32 [EGR_NUM_STEPS][H*W], host pointer; pixels outside this context's partition read 0. Parity tests use it to LIST the
+ * pixels whose bounce rays met a different number of hits than the CPU oracle's. Synchronises. */
+int egr_debug_get_step_hits(egr_context *ctx, int32_t *host_out, void *hip_stream);
 /* BVH self-check: every leaf box equals its instance box, every internal box is the union of its children,
  * every visible instance is reachable exactly once. Returns 0 if consistent. Host-side; synchronises. */
 int egr_debug_check_bvh(egr_context *ctx, void *hip_stream);

@@ -56,7 +56,7 @@ class _Targets(ctypes.Structure):
 
 _OUT_F64 = ["output_rgb", "output_depth", "output_normal", "output_f0", "output_roughness", "output_transmittance",
             "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final"]
-_OUT_INT = ["random_seeds", "num_traversed", "num_accumulated", "num_composited_all_steps", "effective_steps"]
+_OUT_INT = ["random_seeds", "num_traversed", "num_accumulated", "num_composited_all_steps", "effective_steps", "num_composited_per_step"]
 _OUT_GRAD = ["dL_drgb", "dL_dnormal", "dL_df0", "dL_droughness", "dL_dopacity", "dL_dscale", "dL_dmean", "dL_drotation",
              "total_weight"]
 
@@ -80,6 +80,7 @@ def lib():
         L.orc_set_gaussians.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8
         L.orc_set_use_bvh.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_set_partition.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_set_pixel_mask.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_update_bvh.argtypes = [ctypes.c_void_p]
         L.orc_reset_accumulators.argtypes = [ctypes.c_void_p]
         L.orc_raytrace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
@@ -154,6 +155,14 @@ class Oracle:
     def set_partition(self, rank, world, tile=16):
         self.L.orc_set_partition(self.h, int(rank), int(world), int(tile))
 
+    def set_pixel_mask(self, mask):
+        """Test hook: only pixels with mask != 0 are traced (None = all); the others write nothing, like another rank's tiles."""
+        if mask is None:
+            self.L.orc_set_pixel_mask(self.h, None)
+        else:
+            m = np.ascontiguousarray(np.asarray(mask).reshape(self.H * self.W) != 0, dtype=np.uint8)
+            self.L.orc_set_pixel_mask(self.h, m.ctypes.data_as(ctypes.c_void_p))
+
     def set_gaussians(self, g):
         """g: dict with raw (pre-activation) arrays rgb[N,3] normal[N,3] f0[N,3] roughness[N,1] opacity[N,1]
         scale[N,3] mean[N,3] rotation[N,4] (core/gaussians.h:6-13)."""
@@ -206,8 +215,9 @@ class Oracle:
         for k in _OUT_F64:
             out[k] = np.zeros(shp[k], np.float64)
         out["random_seeds"] = np.zeros((H, W, 1), np.uint32)
-        for k in _OUT_INT[1:]:
+        for k in _OUT_INT[1:5]:
             out[k] = np.zeros((H, W), np.int32)
+        out["num_composited_per_step"] = np.zeros((NSTEPS, H, W), np.int32)
         n = self.n
         gshape = {"dL_drgb": (n, 3), "dL_dnormal": (n, 3), "dL_df0": (n, 3), "dL_droughness": (n, 1), "dL_dopacity": (n, 1),
                   "dL_dscale": (n, 3), "dL_dmean": (n, 3), "dL_drotation": (n, 4), "total_weight": (n, 1)}

@@ -20,7 +20,7 @@ def _expon_lr():
     src = open(os.path.join(ROOT, PKG, "trainer.py")).read()
     tree = ast.parse(src)
     fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "expon_lr")
-    ns = {"np": np}
+    ns = {"np": np, "math": math}
     exec(compile(ast.Module([fn], []), "trainer.expon_lr", "exec"), ns)
     return ns["expon_lr"]
 
@@ -98,6 +98,47 @@ def test_fused_step_matches_torch_adam(scale_decay):
 
 
 @pytest.mark.gpu
+def test_reset_state_keeps_the_step_count_like_replace_tensor_to_optimizer():
+    """scene/gaussian_model.py:464-476 zeroes exp_avg / exp_avg_sq of one group and re-attaches the SAME state dict, so torch's
+    per-tensor `step` - the bias correction - carries on. The fused step must do the same: after 5 steps and a reset of "opacity"
+    the next update equals torch.optim.Adam's on a state whose moments were zeroed in place."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; the product has no CPU fallback")
+    ren = importlib.import_module(PKG + ".renderer")
+    syn = importlib.import_module(PKG + ".synthetic")
+    tr = importlib.import_module(PKG + ".trainer")
+    N = 4000
+    g = syn.make_scene(N, "trained", seed=6)
+    pa, pb = ren.GaussianParams(g), ren.GaussianParams(g)
+    ra, rb = ren.GaussianRaytracer(pa, 32, 32), ren.GaussianRaytracer(pb, 32, 32)
+    opt = torch.optim.Adam([{"params": [getattr(pb, attr)], "lr": LRS[name], "name": name} for name, attr, _ in tr.GROUPS], lr=0.0, eps=1e-15)
+    fused = tr.FusedTrainStep(pa, ra, LRS)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for it in range(8):
+        if it == 5:  # opacity reset (train.py resets opacities every opacity_reset_interval): new values, zero moments, same step count
+            new_opa = torch.full_like(pa._opacity, -2.0)
+            pa._opacity.copy_(new_opa), pb._opacity.data.copy_(new_opa)
+            fused.reset_state("opacity")
+            st = opt.state[pb._opacity]
+            st["exp_avg"].zero_(), st["exp_avg_sq"].zero_()  # what replace_tensor_to_optimizer leaves behind (`step` untouched)
+            assert int(st["step"]) == 5
+        for _, attr, rtname in tr.GROUPS:
+            d = torch.randn(getattr(pa, attr).shape, device="cuda", generator=gen) * 1e-2
+            for pc, rt in ((pa, ra), (pb, rb)):
+                getattr(rt.cuda_module.get_gaussians(), rtname).grad.copy_(d)
+        before = pa._opacity.clone()
+        fused.step()
+        reference_sequence(pb, rb.cuda_module.get_gaussians(), opt, 1.0)
+        for name, attr, _ in tr.GROUPS:
+            a, b = getattr(pa, attr), getattr(pb, attr)
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (it, name, float((a - b).abs().max()))
+        if it == 5:  # the first update after the reset is (1-b1)/sqrt(1-b2) * sqrt(1-b2^6)/(1-b1^6) ~ 0.52 lr, not lr (a restarted count)
+            ratio = float(((pa._opacity - before).abs() / LRS["opacity"]).median())
+            want = (1 - 0.9) / (1 - 0.9 ** 6) / math.sqrt((1 - 0.999) / (1 - 0.999 ** 6))
+            assert abs(ratio - want) < 1e-3 * want, (ratio, want)
+
+
+@pytest.mark.gpu
 def test_fused_step_full_size_timing():
     ren = importlib.import_module(PKG + ".renderer")
     syn = importlib.import_module(PKG + ".synthetic")
@@ -126,4 +167,7 @@ def test_fused_step_full_size_timing():
     print(f"host step at N=1M: fused {t_fused:.3f} ms vs stock torch sequence {t_torch:.3f} ms")
     assert t_fused < t_torch
     with pytest.raises(RuntimeError):
-        torch.ops.egr.fused_adam_step([pc._xyz], [pc._xyz.grad], [], [], [], [], [1.0], [-math.inf], [math.inf], [1.0], 1, 0.9, 0.999, 1e-15, [])
+        torch.ops.egr.fused_adam_step([pc._xyz], [pc._xyz.grad], [], [], [], [], [1.0], [-math.inf], [math.inf], [1.0], 1, 0.9, 0.999, 1e-15)
+    with pytest.raises(RuntimeError):  # a per-group step list of the wrong length is rejected, not silently ignored
+        torch.ops.egr.fused_adam_step([pc._xyz], [pc._xyz.grad], [pc._xyz], [pc._xyz.grad], [pc._xyz], [pc._xyz], [1.0], [-math.inf], [math.inf], [1.0], 1, 0.9,
+                                      0.999, 1e-15, [1, 2])

@@ -338,3 +338,36 @@ def test_parity_metric_is_at_least_as_strict_as_the_reference_psnr():
         assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=2e-3), (i, got, want)
         for k in range(a.shape[0]):  # ours on a single image never exceeds the reference's value for that image
             assert ours(a[k], b[k]) <= float(want[k, 0]) + 2e-3, (i, k)
+
+
+def test_pixel_mask_and_per_step_counts(orc, syn):
+    """Test hooks used by the listed-pixel gradient comparison (tests/hip_common.py): the per-step composited counts are consistent
+    with the reference-defined statistics, and gradients are additive over a pixel mask and its complement (pixels are independent,
+    shaders.cu:77-173 has no cross-pixel state)."""
+    W, H = 40, 24
+    g = syn.make_scene(1200, "trained", seed=12)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    o = orc.Oracle(W, H, double=True, threads=2)
+    o.set_camera(cam["origin"], cam["c2w"], cam["fov"])
+    o.set_config(jitter_primary_rays=0, **syn.TRAIN_LOSS_WEIGHTS)
+    o.set_gaussians(g)
+    o.update_bvh()
+    full = o.raytrace(True, targets=tg)
+    per = full["num_composited_per_step"]
+    assert per.shape == (3, H, W) and np.array_equal(per.sum(0), full["num_composited_all_steps"])
+    last = np.take_along_axis(per, (full["effective_steps"] - 1)[None], 0)[0]
+    assert np.array_equal(last, full["num_accumulated"])  # Q6: the statistic shows the last executed step only
+    assert per[1:].sum() > 0  # bounces happen on this scene
+    rng = np.random.default_rng(0)
+    mask = rng.random((H, W)) < 0.4
+    parts = []
+    for mk in (mask, ~mask):
+        o.set_pixel_mask(mk)
+        o.total_num_calls -= 1
+        parts.append(o.raytrace(True, targets=tg))
+        assert np.all(parts[-1]["num_composited_per_step"][:, ~mk] == 0)
+    o.set_pixel_mask(None)
+    for k in ("dL_dmean", "dL_drgb", "dL_dopacity", "dL_drotation", "total_weight"):
+        s = parts[0][k] + parts[1][k]
+        assert np.abs(s - full[k]).max() <= 1e-12 * np.abs(full[k]).max(), k
