@@ -6,7 +6,7 @@ One "step" = one training-iteration pass of the hot path behind the reference's 
 LBVH refit), raytrace (forward + in-kernel loss gradient + backward), gradient all-reduce over ranks, gradient
 import). A "ray" = one (pixel, bounce-step) traversal; rays/step come from the kernels' own counters.
 
-  python bench.py                       # config C, 1 GPU: the trained-like cloud (headline) and the literal dense-init cloud
+  python bench.py                       # config C, 1 GPU: the literal dense-init cloud (`value`) and the trained-like cloud (`value_trained_like`)
   python bench.py --config B            # BASELINE config 2: 100k Gaussians, 1080p, forward only (measure_fps.py protocol)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
@@ -27,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r2"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh)
+ROUND = "r3"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
 
 
 def parse():
@@ -54,7 +54,7 @@ def parse():
     if a.gaussians is None:
         a.gaussians = 100_000 if a.config == "B" else 1_000_000
     if a.variant is None:
-        a.variant = "init" if a.config == "B" else "trained"
+        a.variant = "init"  # the north star's "synthetic dense-init Gaussian cloud" (init_opa 0.1, config.py:44); the trained-like cloud runs second
     return a
 
 
@@ -226,29 +226,37 @@ def main():
             if not a.forward_only:
                 cands["backward_chain"] = sum(algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank) for s in range(3))
             dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
-            achieved = cands[dom] / (kern[dom] * 1e-3) / 1e9
-            # HBM traffic of the same kernel: rocprofv3 --pmc passes of THIS command collected in THIS round by tools/profile.sh
-            # (separate FETCH_SIZE / WRITE_SIZE passes; units of KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)
-            # and committed as profiles/<round>/pmc_summary.json. bench.py cannot run the profiler around itself.
-            traffic, traffic_src = None, None
+            # HBM traffic per kernel: rocprofv3 --pmc passes of THIS workload collected in THIS round by tools/profile.sh (separate
+            # FETCH_SIZE / WRITE_SIZE passes; units of KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md) and committed
+            # as profiles/<round>/pmc_summary.json, keyed by workload. bench.py cannot run the profiler around itself.
+            pmc = {}
             try:
                 pj = os.path.join(ROOT, "profiles", ROUND, "pmc_summary.json")
-                if os.path.exists(pj) and world == 1 and a.emulate_world <= 1 and a.config == "C" and variant == "trained" and N == 1_000_000:
-                    pm = json.load(open(pj)).get(dom)
-                    if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                        traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                        traffic_src = f"profiles/{ROUND}/pmc_summary.json (rocprofv3 --pmc, this round, same command; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
+                if os.path.exists(pj) and world == 1 and a.emulate_world <= 1 and N == (100_000 if a.config == "B" else 1_000_000) and (W, H) == (1920, 1080):
+                    pmc = json.load(open(pj)).get(f"{a.config}_{variant}", {})
             except Exception:
-                traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_ms": round(kern[dom], 4), "algorithmic_bytes_per_launch": cands[dom],
-                    "evaluated_frac": round((fwd_eval if dom == "forward_chain" else cands[dom]) / (kern[dom] * 1e-3) / 1e9 / 8000.0, 5),
-                    "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
-                    "Hc_source": "one exact-statistics launch of the same frame on the GPU (cube boxes; reference-defined count)",
-                    "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
-                    "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
-                    "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
-                    "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2)}
+                pmc = {}
+
+            def roof_of(k):
+                achieved = cands[k] / (kern[k] * 1e-3) / 1e9
+                pm, traffic, src = pmc.get(k), None, None
+                if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+                    src = f"profiles/{ROUND}/pmc_summary.json[{a.config}_{variant}] (rocprofv3 --pmc, this round, same workload; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
+                return {"bound": "hbm", "kernel": k, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                        "traffic": traffic, "traffic_over_algorithmic": round(traffic / cands[k], 3) if traffic else None, "traffic_source": src,
+                        "avg_kernel_ms": round(kern[k], 4), "algorithmic_bytes_per_launch": cands[k]}
+
+            roof = roof_of(dom)
+            roof.update({"evaluated_frac": round((fwd_eval if dom == "forward_chain" else cands[dom]) / (kern[dom] * 1e-3) / 1e9 / 8000.0, 5),
+                         "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
+                         "Hc_source": "one exact-statistics launch of the same frame on the GPU (cube boxes; reference-defined count)",
+                         "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
+                         "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
+                         "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
+                         "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2),
+                         "other_kernels": [roof_of(k) for k in cands if k != dom and k in kern]})
+            res["device_bytes"] = int(cc[14])
         res["roofline"], res["kernel_ms"] = roof, {k: round(v, 4) for k, v in kern.items()}
         del rt, pc
         torch.cuda.empty_cache()
@@ -257,13 +265,14 @@ def main():
     what = "forward only (no_grad, no BVH update between frames: measure_fps.py protocol)" if a.forward_only else \
         "one training iteration: export + update_bvh + forward + backward + grad import"
     label = {"trained": "trained-like opacity 0.8: reflection bounces happen, three steps per pixel", "init": "literal dense-init opacity 0.1 (config.py:44): Kc ~ 22 per ray, bounces mostly die"}
+    vkey = {"trained": "value_trained_like", "init": "value_dense_init"}
     main_res = run_variant(a.variant, True, not a.no_cpu_baseline)
     other = None
     if a.config == "C" and world == 1 and not a.no_second_variant and a.emulate_world <= 1 and not a.forward_only:
         ov = "init" if a.variant == "trained" else "trained"
         r2 = run_variant(ov, True, False)
         other = {"variant": ov, "value": round(r2["value"], 3), "unit": "Mrays/s", "ms_per_step": round(r2["ms_per_step"], 4), "status": r2["status"],
-                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"]}
+                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"], "device_bytes": r2.get("device_bytes")}
     if rank == 0:
         line = {
             "metric": "Mrays/s fwd+bwd @1080p, 1M Gaussians" if a.config == "C" and not a.forward_only else "Mrays/s fwd-only @1080p",
@@ -274,7 +283,8 @@ def main():
                                    f"the other variant is in `other_variant`), N={N}, {W}x{H}, {what}, num_bounces={a.bounces}, jitter on, reference default config",
                        "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients"},
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"], "kernel_ms": main_res["kernel_ms"],
-            "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None,
+            "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None, "device_bytes": main_res.get("device_bytes"),
+            vkey[a.variant]: round(main_res["value"], 3), vkey["init" if a.variant == "trained" else "trained"]: (other or {}).get("value"),
             "note": "vs_baseline null: the reference publishes no throughput number; PSNR vs OptiX is unmeasurable here (no NVIDIA "
                     "hardware), parity is against the CPU oracle (tests/).",
         }

@@ -189,6 +189,9 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
         out->status = w[CW_STATUS];
         out->bvh_depth = c->max_depth;
         out->bucket_records = w[CW_BUCKET_RECORDS];
+        out->device_bytes = (uint64_t)c->device_bytes;
+        out->arena_blocks_used = w[CW_HIT_BUMP], out->arena_blocks_cap = c->hit_blocks_cap;
+        out->ext_blocks_used = w[CW_EXT_BUMP], out->ext_blocks_cap = c->ext_blocks_cap;
         if (getenv("EGR_DEBUG_EXT")) fprintf(stderr, "[egr] extension blocks used %u of %u, cand_cap %u\n", w[CW_EXT_BUMP], c->ext_blocks_cap, c->cand_cap);
         if (getenv("EGR_PRINT_TRAVERSAL_STATS")) {
             for (int k = 0; k < 2; k++)

@@ -305,21 +305,18 @@ __global__ void __launch_bounds__(BS) k_refit_wide_level(uint32_t begin, uint32_
     wnodes[(size_t)w * EGR_WIDTH + k] = pack_box(lo, hi, link);
 }
 
-template <class T> void dfree(T *&p) {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-}
-template <class T> void dalloc(T *&p, size_t count) {
-    dfree(p);
-    EGR_HIP(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
-}
 
 } // namespace
 
+template <class T> static void dalloc(egr_context *c, T *&p, size_t count) {
+    egr_dev_free(c, p);
+    egr_dev_alloc(c, p, count);
+}
+
 void egr_bvh_free(egr_context *c) {
-    dfree(c->wnodes), dfree(c->pos_of_gid), dfree(c->inst_w), dfree(c->inst_m), dfree(c->app), dfree(c->aabb), dfree(c->grad_rows);
-    dfree(c->sort_tmp), dfree(c->keys_in), dfree(c->keys_out), dfree(c->vals_in), dfree(c->vals_out);
-    dfree(c->k_left), dfree(c->k_right), dfree(c->k_parent), dfree(c->k_first), dfree(c->k_last), dfree(c->wide_of), dfree(c->scratch_u32), dfree(c->out_of_frame);
+    egr_dev_free(c, c->wnodes), egr_dev_free(c, c->pos_of_gid), egr_dev_free(c, c->inst_w), egr_dev_free(c, c->inst_m), egr_dev_free(c, c->app), egr_dev_free(c, c->aabb), egr_dev_free(c, c->grad_rows);
+    egr_dev_free(c, c->sort_tmp), egr_dev_free(c, c->keys_in), egr_dev_free(c, c->keys_out), egr_dev_free(c, c->vals_in), egr_dev_free(c, c->vals_out);
+    egr_dev_free(c, c->k_left), egr_dev_free(c, c->k_right), egr_dev_free(c, c->k_parent), egr_dev_free(c, c->k_first), egr_dev_free(c, c->k_last), egr_dev_free(c, c->wide_of), egr_dev_free(c, c->scratch_u32), egr_dev_free(c, c->out_of_frame);
     c->n_alloc = 0;
     c->n_built = 0;
     c->bvh_valid = false;
@@ -328,26 +325,26 @@ void egr_bvh_free(egr_context *c) {
 void egr_bvh_reserve(egr_context *c, uint32_t n) {
     if (n <= c->n_alloc && c->wnodes) return;
     uint32_t cap = std::max<uint32_t>(n + n / 8, 256); // head-room: the reference grows by +75k far-field points
-    dalloc(c->wnodes, (size_t)cap * EGR_WIDTH + 64);   // <= n-1 wide nodes (one per binary internal node, usually ~n/5)
-    dalloc(c->pos_of_gid, cap);
-    dalloc(c->inst_w, 4 * (size_t)cap);
-    dalloc(c->inst_m, 4 * (size_t)cap);
-    dalloc(c->grad_rows, 32 * (size_t)cap);
+    dalloc(c, c->wnodes, (size_t)cap * EGR_WIDTH + 64);   // <= n-1 wide nodes (one per binary internal node, usually ~n/5)
+    dalloc(c, c->pos_of_gid, cap);
+    dalloc(c, c->inst_w, 4 * (size_t)cap);
+    dalloc(c, c->inst_m, 4 * (size_t)cap);
+    dalloc(c, c->grad_rows, 32 * (size_t)cap);
     EGR_HIP(hipMemset(c->grad_rows, 0, 32 * (size_t)cap * sizeof(float)));
-    dalloc(c->app, 3 * (size_t)cap);
-    dalloc(c->aabb, 6 * (size_t)cap);
-    dalloc(c->keys_in, cap), dalloc(c->keys_out, cap), dalloc(c->vals_in, cap), dalloc(c->vals_out, cap);
-    dalloc(c->k_left, cap), dalloc(c->k_right, cap), dalloc(c->k_parent, 2 * (size_t)cap);
-    dalloc(c->k_first, cap), dalloc(c->k_last, cap), dalloc(c->wide_of, cap);
-    if (!c->scratch_u32) dalloc(c->scratch_u32, 64);
+    dalloc(c, c->app, 3 * (size_t)cap);
+    dalloc(c, c->aabb, 6 * (size_t)cap);
+    dalloc(c, c->keys_in, cap), dalloc(c, c->keys_out, cap), dalloc(c, c->vals_in, cap), dalloc(c, c->vals_out, cap);
+    dalloc(c, c->k_left, cap), dalloc(c, c->k_right, cap), dalloc(c, c->k_parent, 2 * (size_t)cap);
+    dalloc(c, c->k_first, cap), dalloc(c, c->k_last, cap), dalloc(c, c->wide_of, cap);
+    if (!c->scratch_u32) dalloc(c, c->scratch_u32, 64);
     if (!c->out_of_frame) {
-        dalloc(c->out_of_frame, 1);
+        dalloc(c, c->out_of_frame, 1);
         EGR_HIP(hipMemset(c->out_of_frame, 0, sizeof(uint32_t)));
     }
     size_t bytes = 0;
     EGR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)cap, 0, 63, 0));
-    dfree(c->sort_tmp);
-    EGR_HIP(hipMalloc(&c->sort_tmp, bytes));
+    egr_dev_free(c, c->sort_tmp);
+    egr_dev_alloc_raw(c, &c->sort_tmp, bytes);
     c->sort_tmp_bytes = bytes;
     c->n_alloc = cap;
     c->bvh_valid = false;

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_atrous(int W, int H, int hole, float in
 void egr_denoise_atrous(egr_context *c, hipStream_t s) {
     const int W = c->width, H = c->height;
     const size_t n = (size_t)W * H * 3;
-    if (!c->denoise_tmp) EGR_HIP(hipMalloc((void **)&c->denoise_tmp, 2 * n * sizeof(float)));
+    if (!c->denoise_tmp) egr_dev_alloc(c, c->denoise_tmp, 2 * n);
     float *tmp[2] = {c->denoise_tmp, c->denoise_tmp + n};
     const float *src = c->fb.output_final;
     const dim3 grid((W + 31) / 32, (H + 7) / 8), block(256);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/egr_raytracer.h"
@@ -196,7 +197,24 @@ struct egr_context {
     std::vector<KernelStamp> stamps;
     size_t stamps_used = 0;
     std::string last_error;
+    // device memory this context holds (egr_counters::device_bytes): every allocation goes through egr_dev_alloc / egr_dev_free
+    std::unordered_map<void *, size_t> alloc_sizes;
+    size_t device_bytes = 0;
 };
+
+inline void egr_dev_alloc_raw(egr_context *c, void **p, size_t bytes) {
+    EGR_HIP(hipMalloc(p, bytes));
+    c->alloc_sizes[*p] = bytes, c->device_bytes += bytes;
+}
+template <class T> void egr_dev_alloc(egr_context *c, T *&p, size_t count) { egr_dev_alloc_raw(c, (void **)&p, (count ? count : 1) * sizeof(T)); }
+template <class T> void egr_dev_free(egr_context *c, T *&p) {
+    if (p) {
+        auto it = c->alloc_sizes.find((void *)p);
+        if (it != c->alloc_sizes.end()) c->device_bytes -= it->second, c->alloc_sizes.erase(it);
+        (void)hipFree((void *)p);
+    }
+    p = nullptr;
+}
 
 // bvh.hip
 void egr_bvh_free(egr_context *c);

@@ -494,11 +494,6 @@ __global__ void k_copy3(const float *__restrict__ src, float *__restrict__ dst, 
     if (i < n) dst[i] = src[i];
 }
 
-template <class T> void dfree(T *&p) {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-}
-
 } // namespace
 
 uint32_t egr_num_tasks_for_rank(const egr_context *c) {
@@ -518,7 +513,7 @@ void egr_build_task_order(egr_context *c) {
         }
     if (c->task_orders.size() >= 8) { // a caller cycling through many partitions: drop the cache (nothing may still read the tables)
         EGR_HIP(hipDeviceSynchronize());
-        for (auto &o : c->task_orders) (void)hipFree(o.table);
+        for (auto &o : c->task_orders) egr_dev_free(c, o.table);
         c->task_orders.clear();
     }
     const uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
@@ -538,16 +533,16 @@ void egr_build_task_order(egr_context *c) {
     std::vector<uint32_t> order(std::max<size_t>(keyed.size(), 1), 0u);
     for (size_t i = 0; i < keyed.size(); i++) order[i] = keyed[i].second;
     uint32_t *table = nullptr;
-    EGR_HIP(hipMalloc((void **)&table, order.size() * sizeof(uint32_t)));
+    egr_dev_alloc(c, table, order.size());
     EGR_HIP(hipMemcpy(table, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); // pageable source: returns after the copy
     c->task_orders.push_back({c->rank, c->world, table});
     c->task_macro = table;
 }
 
 void egr_trace_free(egr_context *c) {
-    for (auto &o : c->task_orders) (void)hipFree(o.table);
+    for (auto &o : c->task_orders) egr_dev_free(c, o.table);
     c->task_orders.clear(), c->task_macro = nullptr;
-    dfree(c->stack_spill), dfree(c->cand_keys), dfree(c->cand_vals), dfree(c->cand_queue), dfree(c->hit_arena), dfree(c->task_last_block), dfree(c->state), dfree(c->control), dfree(c->queues), dfree(c->denoise_tmp), dfree(c->ext_keys), dfree(c->ext_vals);
+    egr_dev_free(c, c->stack_spill), egr_dev_free(c, c->cand_keys), egr_dev_free(c, c->cand_vals), egr_dev_free(c, c->cand_queue), egr_dev_free(c, c->hit_arena), egr_dev_free(c, c->task_last_block), egr_dev_free(c, c->state), egr_dev_free(c, c->control), egr_dev_free(c, c->queues), egr_dev_free(c, c->denoise_tmp), egr_dev_free(c, c->ext_keys), egr_dev_free(c, c->ext_vals);
     for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -575,26 +570,26 @@ void egr_trace_alloc(egr_context *c) {
     const size_t S = (size_t)c->strands; // every strand owns a full set of resident-wave scratch slots
     uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * (double)S * EGR_WAVE * 16.0)); // key 4 + value 8 + queue 4 bytes
     c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384) & ~7u;
-    EGR_HIP(hipMalloc((void **)&c->cand_keys, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float)));
-    EGR_HIP(hipMalloc((void **)&c->cand_vals, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2)));
-    EGR_HIP(hipMalloc((void **)&c->cand_queue, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t)));
+    egr_dev_alloc_raw(c, (void **)&c->cand_keys, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float));
+    egr_dev_alloc_raw(c, (void **)&c->cand_vals, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2));
+    egr_dev_alloc_raw(c, (void **)&c->cand_queue, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t));
     // extension blocks: 1/8 of the forward byte budget on top (12 B per entry), at least 64 blocks
     c->ext_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(fwd_bytes / 8.0 / (12.0 * EGR_EXT_BLOCK)), 64), 65536);
-    EGR_HIP(hipMalloc((void **)&c->ext_keys, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float)));
-    EGR_HIP(hipMalloc((void **)&c->ext_vals, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float2)));
-    EGR_HIP(hipMalloc((void **)&c->stack_spill, S * c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t)));
+    egr_dev_alloc_raw(c, (void **)&c->ext_keys, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float));
+    egr_dev_alloc_raw(c, (void **)&c->ext_vals, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float2));
+    egr_dev_alloc_raw(c, (void **)&c->stack_spill, S * c->num_slots * EGR_GSTK * EGR_WAVE * sizeof(uint32_t));
     const double bwd_bytes = (double)c->bwd_capacity * 36.0; // the reference's ppll_backward_size entries x 36 B: all of it is arena
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
-    EGR_HIP(hipMalloc((void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
-    EGR_HIP(hipMalloc((void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * sizeof(uint32_t)));
+    egr_dev_alloc_raw(c, (void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4));
+    egr_dev_alloc_raw(c, (void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * sizeof(uint32_t));
     c->state_stride = c->num_tasks_total * EGR_WAVE;
-    EGR_HIP(hipMalloc((void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
+    egr_dev_alloc_raw(c, (void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float));
     EGR_HIP(hipMemset(c->state, 0, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
-    EGR_HIP(hipMalloc((void **)&c->control, CW_COUNT * sizeof(uint32_t)));
+    egr_dev_alloc_raw(c, (void **)&c->control, CW_COUNT * sizeof(uint32_t));
     EGR_HIP(hipMemset(c->control, 0, CW_COUNT * sizeof(uint32_t)));
     EGR_HIP(hipHostMalloc((void **)&c->control_host, CW_COUNT * sizeof(uint32_t)));
-    EGR_HIP(hipMalloc((void **)&c->queues, EGR_QUEUE_WORDS * S * sizeof(uint32_t)));
+    egr_dev_alloc_raw(c, (void **)&c->queues, EGR_QUEUE_WORDS * S * sizeof(uint32_t));
     EGR_HIP(hipMemset(c->queues, 0, EGR_QUEUE_WORDS * S * sizeof(uint32_t)));
     if (c->strands > 1) {
         EGR_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

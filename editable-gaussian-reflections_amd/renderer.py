@@ -38,6 +38,31 @@ class GaussianParams:
     def parameters(self):
         return [self._xyz, self._opacity, self._scaling, self._rotation, self._diffuse, self._normal, self._roughness, self._f0]
 
+    _NAMES = ("_xyz", "_opacity", "_scaling", "_rotation", "_diffuse", "_normal", "_roughness", "_f0")
+
+    @torch.no_grad()
+    def prune_points(self, mask):
+        """scene/gaussian_model.py:493-531 `prune_points(mask)`: rows with mask == True are REMOVED; every parameter is re-created
+        from the kept rows with a fresh zero `.grad` (the gradient of the iteration in flight is dropped, like upstream)."""
+        keep = ~mask
+        for name in self._NAMES:
+            t = getattr(self, name)[keep].contiguous()
+            t.grad = torch.zeros_like(t)
+            setattr(self, name, t)
+
+    @torch.no_grad()
+    def append_points(self, new):
+        """scene/gaussian_model.py:533-585 `cat_tensors_to_optimizer` + `densification_postfix` (add_farfield_points): rows are
+        appended to every parameter, gradients restart at zero. `new`: dict with the reference's raw attribute names
+        (mean, opacity, scale, rotation, rgb, normal, roughness, f0)."""
+        src = dict(_xyz="mean", _opacity="opacity", _scaling="scale", _rotation="rotation", _diffuse="rgb", _normal="normal", _roughness="roughness", _f0="f0")
+        for name in self._NAMES:
+            old = getattr(self, name)
+            add = torch.as_tensor(np.asarray(new[src[name]]), dtype=torch.float32, device=old.device).reshape(-1, old.shape[1])
+            t = torch.cat([old, add], 0).contiguous()
+            t.grad = torch.zeros_like(t)
+            setattr(self, name, t)
+
     # getters read by _export_param_values (gaussian_raytracer.py:41-50); an EditableGaussianModel overrides these
     get_scaling = property(lambda s: torch.exp(s._scaling))
     _get_scaling = property(lambda s: s._scaling)
@@ -184,6 +209,20 @@ def render(camera, raytracer: GaussianRaytracer, targets_available=True, force_u
                            normal=cl(fb.output_normal), roughness=cl(fb.output_roughness), f0=cl(fb.output_f0), target=tg["original_image"],
                            target_diffuse=tg["diffuse_image"], target_specular=tg["specular_image"], target_depth=tg["depth_image"],
                            target_normal=tg["normal_image"], target_roughness=tg["roughness_image"], target_f0=tg["f0_image"])
+
+
+def camera_from_RT(R, T, FoVy, device="cuda", **images):
+    """What scene/cameras.py:22-152 holds for a view, from the dataset's (R, T, FovY) (dataset/blender_dataset.py:62-75: R is the
+    camera-to-world rotation in COLMAP axes - "stored transposed" -, T the world-to-camera translation): `R` unchanged, `FoVy`, and
+    `camera_center` = the translation of the inverse world-to-view matrix (Camera.update via getWorld2View2) = -R T. Pinned by
+    tests/golden/reference_cameras.npz, generated by running the reference's Camera class."""
+    R = np.asarray(R, np.float64)
+    centre = -R @ np.asarray(T, np.float64)
+    cam = SimpleNamespace(R=R.astype(np.float32), T=np.asarray(T, np.float32), FoVy=float(FoVy),
+                          camera_center=torch.as_tensor(centre.astype(np.float32), device=device))
+    for k, v in images.items():
+        setattr(cam, k, v)
+    return cam
 
 
 def camera_from_c2w(origin, c2w_blender, fov, **images):

@@ -57,10 +57,15 @@ class FusedTrainStep:
     @torch.no_grad()
     def prune(self, keep_mask):
         """gaussian_model.py `_prune_optimizer`: keep the rows of both moments where `keep_mask` is True. The caller prunes the
-        parameters themselves and calls raytracer.rebuild_bvh()."""
+        parameters themselves (`pc.prune_points(~keep_mask)`) and calls raytracer.rebuild_bvh().
+        train.py:238-249 prunes BETWEEN render() and optimizer.step(): upstream the raytracer gradients of that iteration were
+        already added to the old parameters' `.grad`, which prune_points replaces by zeros, so the step that follows sees a zero
+        gradient. Here the import happens inside the fused step, so the iteration's raytracer gradients are dropped now
+        (resize() would otherwise keep their first rows, misaligned with the pruned model)."""
         for name in self.exp_avg:
             self.exp_avg[name] = self.exp_avg[name][keep_mask].contiguous()
             self.exp_avg_sq[name] = self.exp_avg_sq[name][keep_mask].contiguous()
+        self.rt.zero_grad()
 
     @torch.no_grad()
     def extend(self, n_new):

@@ -105,6 +105,10 @@ typedef struct egr_counters {
     uint32_t status;                     /* EGR_STATUS_* bit mask of the last launch                          */
     uint32_t bvh_depth;
     uint32_t bucket_records;             /* 64-B gradient records the bounce-step backward added to the rows (grad launches) */
+    uint64_t device_bytes;               /* device memory this context holds right now (scratch, arena, ray state, tree, records);
+                                          * the caller's tensors (parameters, gradients, framebuffer) are not included          */
+    uint32_t arena_blocks_used, arena_blocks_cap; /* composited-hit arena (backward capacity): 9-KB blocks the last grad launch took / holds */
+    uint32_t ext_blocks_used, ext_blocks_cap;     /* candidate-list extension blocks (forward capacity) the last launch took / holds         */
 } egr_counters;
 
 #define EGR_STATUS_OK 0u

@@ -421,3 +421,37 @@ def test_arbitrary_cameras(ren, orc, syn, seed):
     assert min(lv.values()) > 70, lv
     assert psnr(out["output_rgb"][0], ref["output_rgb"][0]) > 110
     grads_vs_oracle_listing_flipped_pixels(ren, rt, o, cam_obj(ren, cam, tg), tg, W, H, f"camera_{seed}_grads")
+
+
+# ------------------------------------------------------------------------------------------------ P1 against reference output
+def test_caller_mirror_shoots_the_reference_cameras_rays(ren, syn):
+    """P1 / T4 pinned by REFERENCE OUTPUT, not by the oracle: the cameras of tests/golden/reference_cameras.npz (scene/cameras.py
+    `Camera` run on (R, T, FoVy); rays from `compute_primary_ray_directions` the way prepare_initial_ply.py:58-66 calls it) go
+    through renderer.camera_from_RT -> GaussianRaytracer.__call__ (pose flip, set_pose, fov) into the HIP tracer inside the closed
+    synthetic room. Step 0 logs the bounce ray (shaders.cu:141-146): next_origin = origin + depth * dir + eps * next_dir, so the
+    primary direction the kernel used is normalize(next_origin - eps * next_dir - camera_center) - compared with the reference's."""
+    z = np.load(os.path.join(GOLD, "reference_cameras.npz"))
+    g = syn.make_scene(20000, "trained", seed=11)
+    worst = 0.0
+    for i in range(int(z["num_cases"])):
+        W, H = (int(x) for x in z[f"c{i}_wh"])
+        rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=20_000_000, ppll_backward_size=1_000_000)
+        m = rt.cuda_module
+        m.get_config().jitter_primary_rays.fill_(False)
+        cam = ren.camera_from_RT(z[f"c{i}_R"], z[f"c{i}_T"], float(z[f"c{i}_FoVy"]))
+        with torch.no_grad():
+            rt(cam)
+        fb = m.get_framebuffer()
+        no, nd = fb.output_ray_origin[0].double().cpu().numpy(), fb.output_ray_direction[0].double().cpu().numpy()
+        depth = fb.output_depth[0, ..., 0].cpu().numpy()
+        hit = (np.abs(nd).sum(-1) > 0) & (depth > 0.2)  # pixels whose step 0 went on to sample a bounce
+        assert hit.mean() > 0.8, (i, hit.mean())  # closed room: (almost) every primary ray lands on a wall or a sphere
+        eps = float(m.get_config().eps_ray_surface_offset)
+        v = no - eps * nd - z[f"c{i}_camera_center"].astype(np.float64)
+        d = v / np.linalg.norm(v, axis=-1, keepdims=True)
+        err = np.abs(d - z[f"c{i}_dirs"])[hit].max()
+        worst = max(worst, float(err))
+        assert err < 5e-6, (i, err)  # fp32 position round-off over a depth of a few units
+        assert m.get_counters()[11] == 0
+        del rt
+    report("reference_camera_rays", worst_direction_error=f"{worst:.1e}", cameras=int(z["num_cases"]))

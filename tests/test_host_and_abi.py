@@ -68,22 +68,35 @@ def test_make_raytracer_signature_matches_reference():
     assert pkg.GAUSS_TRACER_PATH.endswith("libraytracer.so")
 
 
-def test_pose_convention_matches_reference_helper(orc):
-    """P1: R_blender = -R with column 0 re-negated, then set_pose(camera_center, R_blender). The oracle consuming that
-    rotation reproduces the reference's compute_primary_ray_directions golden vectors (test_oracle_known_answers);
-    here: camera_from_c2w inverts the caller-side conversion exactly."""
+def test_pose_chain_matches_the_reference_camera_class(orc, tmp_path):
+    """P1 against reference OUTPUT (tests/golden/reference_cameras.npz, produced by running scene/cameras.py `Camera`,
+    utils/graphics_utils.py and utils/depth_utils.py `compute_primary_ray_directions`, see make_camera_vectors.py):
+    transforms json -> formats.read_transforms -> (R, T, FovY) -> renderer.camera_from_RT (camera_center) ->
+    GaussianRaytracer.blender_rotation (gaussian_raytracer.py:95-97) -> set_pose -> primary ray of every pixel."""
+    import json
+
     import torch
 
     ren = importlib.import_module(PKG + ".renderer")
-    rng = np.random.default_rng(0)
-    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
-    R = torch.tensor(q, dtype=torch.float32)
-    Rb = ren.GaussianRaytracer.blender_rotation(R.clone())
-    assert torch.equal(Rb[:, 0], R[:, 0]) and torch.equal(Rb[:, 1:], -R[:, 1:])
-    back = Rb.clone()
-    back[:, 0] = -back[:, 0]
-    back = -back
-    assert torch.equal(back, R)
+    fmt = importlib.import_module(PKG + ".formats")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_cameras.npz"))
+    for i in range(int(z["num_cases"])):
+        W, H = (int(x) for x in z[f"c{i}_wh"])
+        path = tmp_path / f"transforms_{i}.json"
+        path.write_text(json.dumps({"camera_angle_x": float(z[f"c{i}_camera_angle_x"]),
+                                    "frames": [{"file_path": "r_0", "transform_matrix": z[f"c{i}_transform_matrix"].tolist()}]}))
+        fr = fmt.read_transforms(str(path), W, H)[0]
+        np.testing.assert_allclose(fr["R"], z[f"c{i}_R"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(fr["T"], z[f"c{i}_T"], rtol=0, atol=1e-12)
+        assert abs(fr["FovY"] - float(z[f"c{i}_FoVy"])) < 1e-12
+        cam = ren.camera_from_RT(fr["R"], fr["T"], fr["FovY"], device="cpu")
+        np.testing.assert_allclose(cam.camera_center.numpy(), z[f"c{i}_camera_center"], rtol=0, atol=2e-6)  # the reference inverts a float32 4x4
+        Rb = ren.GaussianRaytracer.blender_rotation(torch.from_numpy(cam.R).clone())
+        np.testing.assert_allclose(Rb.numpy(), z[f"c{i}_R_blender"].astype(np.float32), rtol=0, atol=0)
+        o = orc.Oracle(W, H)
+        o.set_camera(cam.camera_center.numpy(), Rb.numpy(), cam.FoVy)
+        d = o.primary_rays(jitter=False)
+        assert np.abs(d - z[f"c{i}_dirs"]).max() < 3e-7, (i, np.abs(d - z[f"c{i}_dirs"]).max())  # fp32 oracle vs the reference in fp64
 
 
 def test_tile_partition_covers_image_once():
