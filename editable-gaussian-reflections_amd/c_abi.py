@@ -38,7 +38,7 @@ egr_stats = _struct("egr_stats", [(k, _F) for k in STATS_FIELDS])
 egr_counters = _struct("egr_counters", [("rays", C.c_uint64 * 3), ("candidates", C.c_uint64 * 3), ("composited", C.c_uint64 * 3), ("lifetime_rays", C.c_uint64),
                                         ("lifetime_launches", C.c_uint32), ("status", C.c_uint32), ("bvh_depth", C.c_uint32), ("bucket_records", C.c_uint32),
                                         ("device_bytes", C.c_uint64), ("arena_blocks_used", C.c_uint32), ("arena_blocks_cap", C.c_uint32),
-                                        ("ext_blocks_used", C.c_uint32), ("ext_blocks_cap", C.c_uint32)])
+                                        ("ext_blocks_used", C.c_uint32), ("ext_blocks_cap", C.c_uint32), ("accepted", C.c_uint64 * 3)])
 
 _lib = None
 

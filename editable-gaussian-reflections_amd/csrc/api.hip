@@ -183,7 +183,7 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
         const uint32_t *w = c->control_host;
         auto u64 = [&](int i) { return (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32); };
         for (int s = 0; s < EGR_NSTEPS; s++)
-            out->rays[s] = u64(CW_RAYS + 2 * s), out->candidates[s] = u64(CW_CAND + 2 * s), out->composited[s] = u64(CW_COMP + 2 * s);
+            out->rays[s] = u64(CW_RAYS + 2 * s), out->candidates[s] = u64(CW_CAND + 2 * s), out->composited[s] = u64(CW_COMP + 2 * s), out->accepted[s] = u64(CW_ACCEPTED + 2 * s);
         out->lifetime_rays = u64(CW_LIFE_RAYS);
         out->lifetime_launches = w[CW_LIFE_LAUNCHES];
         out->status = w[CW_STATUS];

@@ -201,6 +201,86 @@ __global__ void __launch_bounds__(BS) k_karras(int n, const uint64_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// SAH-optimal collapse, part 1 (Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through compressed wide
+// BVHs", sec. 4.2, restated for one gaussian per leaf): the walk's cost is the number of 128-B wide nodes a ray enters, and a ray
+// enters a node with probability ~ its surface area, so the best 8-wide tree over a given binary tree minimises the SUM OF THE AREAS
+// OF ITS WIDE NODES (every leaf costs the same wherever it hangs). Dynamic programme over the binary tree, bottom-up:
+//   T(n, i) = least total area of the wide nodes inside subtree n when n may occupy at most i child slots of its parent's wide node
+//   leaf:      T = 0
+//   internal:  T(n, 1) = area(n) + D(n, 8)                       (n becomes a wide node, its 8 slots go to its two children)
+//              T(n, i) = min(D(n, i), T(n, i - 1)),  i = 2..7    (n dissolves into the parent's node)
+//              D(n, j) = min over k = 1..j-1 of T(left, k) + T(right, j - k)
+// One thread per leaf climbs; the second arrival at a node owns it (atomic counter). The tree is spread over all XCDs whose L2s
+// are not coherent (cdna guide, Guideline 16): every payload word is written and read with agent-scope atomic accesses (sc1,
+// write-through / cache-bypassing), the writer drains its stores before the counter RMW, which itself is acq_rel at agent scope.
+// Record per binary internal node: box lo[3], hi[3], T[1..7] (16 floats, 3 unused). Runs once per rebuild.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef EGR_SAH_COLLAPSE
+#define EGR_SAH_COLLAPSE 1 // 0: the round-2 heuristic (open the child with the most leaves / the largest one that dissolves completely)
+#endif
+#define EGR_DP_STRIDE 16
+__device__ __forceinline__ float ld_agent(const float *p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// D(n, j) and the split that attains it, from the children's T rows (index 0 unused; a leaf's row is all zero)
+__device__ __forceinline__ float dp_distribute(const float (&Tl)[8], const float (&Tr)[8], int j, int &best_k) {
+    float best = 3.0e38f;
+    best_k = 1;
+    for (int k = 1; k < j; k++) {
+        const float c = Tl[min(k, 7)] + Tr[min(j - k, 7)];
+        if (c < best) best = c, best_k = k;
+    }
+    return best;
+}
+__global__ void __launch_bounds__(BS) k_sah_bottom_up(int n, const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                                                      const int32_t *__restrict__ parent, const float *__restrict__ aabb,
+                                                      const uint32_t *__restrict__ gid_of_pos, uint32_t *flags, float *dp) {
+    const int j = blockIdx.x * BS + threadIdx.x;
+    if (j >= n) return;
+    int cur = parent[(n - 1) + j];
+    while (cur >= 0) {
+        if (__hip_atomic_fetch_add(&flags[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; // the sibling subtree is not done yet
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        float Tc[2][8];
+        const int ch[2] = {left[cur], right[cur]};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (ch[c] >= n - 1) { // leaf: the gaussian's box (plain loads: written by an earlier kernel), no wide nodes below
+                const float *bx = aabb + 6 * (size_t)gid_of_pos[ch[c] - (n - 1)];
+#pragma unroll
+                for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], bx[a]), hi[a] = fmaxf(hi[a], bx[3 + a]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) Tc[c][i] = 0.0f;
+            } else {
+                const float *r = dp + (size_t)ch[c] * EGR_DP_STRIDE;
+#pragma unroll
+                for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], ld_agent(r + a)), hi[a] = fmaxf(hi[a], ld_agent(r + 3 + a));
+                Tc[c][0] = 0.0f;
+#pragma unroll
+                for (int i = 1; i < 8; i++) Tc[c][i] = ld_agent(r + 5 + i);
+            }
+        }
+        const float dx = fmaxf(hi[0] - lo[0], 0.0f), dy = fmaxf(hi[1] - lo[1], 0.0f), dz = fmaxf(hi[2] - lo[2], 0.0f);
+        const float area = (lo[0] <= hi[0]) ? dx * dy + dy * dz + dz * dx : 0.0f; // (half the surface area; empty box: unusable gaussians only)
+        float T[8];
+        int k_unused;
+        T[0] = 0.0f;
+        T[1] = area + dp_distribute(Tc[0], Tc[1], 8, k_unused);
+        for (int i = 2; i < 8; i++) T[i] = fminf(dp_distribute(Tc[0], Tc[1], i, k_unused), T[i - 1]);
+        float *w = dp + (size_t)cur * EGR_DP_STRIDE;
+#pragma unroll
+        for (int a = 0; a < 3; a++) st_agent(w + a, lo[a]), st_agent(w + 3 + a, hi[a]);
+#pragma unroll
+        for (int i = 1; i < 8; i++) st_agent(w + 5 + i, T[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the record is out before the parent's counter moves
+        cur = parent[cur];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Collapse of the binary tree into 8-wide nodes, one level of the wide tree per launch.
 // frontier_in: binary internal ids that ARE wide nodes of this level (their wide index is wide_of[id]).
 // Children = the binary node's two children, then repeatedly the internal child with the most leaves is replaced by
@@ -210,7 +290,7 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
                                                        const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                                        const uint32_t *__restrict__ first, const uint32_t *__restrict__ last,
                                                        uint32_t *__restrict__ wide_of, uint32_t *__restrict__ counters, // [0] = #wide nodes, [1] = next frontier size
-                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes) {
+                                                       uint32_t *__restrict__ frontier_out, uint4 *__restrict__ wnodes, const float *__restrict__ dp) {
     uint32_t t = blockIdx.x * BS + threadIdx.x;
     if (t >= count) return;
     const int b = (int)frontier_in[t];
@@ -219,7 +299,41 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
     int nchild = 2;
     child[0] = left[b], child[1] = right[b];
     auto leaves_of = [&](int id) -> uint32_t { return id >= n - 1 ? 1u : last[id] - first[id] + 1u; };
-    while (nchild < EGR_WIDTH) {
+#if EGR_SAH_COLLAPSE
+    // SAH-optimal collapse, part 2: replay the dynamic programme's decisions top-down. Every entry carries the number of slots the
+    // optimum grants its subtree; an internal entry with more than one slot is replaced by its two children with the split that
+    // attains D(node, slots) (kept in Morton order) - unless the extra slots do not pay (T(node, i) == T(node, i - 1)).
+    {
+        int budget[EGR_WIDTH];
+        auto row = [&](int id, float (&T)[8]) {
+            T[0] = 0.0f;
+            for (int i = 1; i < 8; i++) T[i] = id >= n - 1 ? 0.0f : dp[(size_t)id * EGR_DP_STRIDE + 5 + i];
+        };
+        {
+            float Tl[8], Tr[8];
+            row(child[0], Tl), row(child[1], Tr);
+            int k;
+            dp_distribute(Tl, Tr, EGR_WIDTH, k);
+            budget[0] = k, budget[1] = EGR_WIDTH - k;
+        }
+        for (int at = 0; at < nchild;) {
+            const int id = child[at];
+            if (id >= n - 1) { at++; continue; } // a leaf takes one slot
+            float T[8], Tl[8], Tr[8];
+            row(id, T), row(left[id], Tl), row(right[id], Tr);
+            int b = min(budget[at], 7), k = 1;
+            // T(id, b) = min(D(id, b), T(id, b - 1)): slots that buy nothing stay empty; at equal cost the flatter tree wins (fewer
+            // nodes; all-zero areas - coincident gaussians - would otherwise keep the binary tree's depth)
+            while (b >= 2 && !(dp_distribute(Tl, Tr, b, k) <= T[b - 1])) b--;
+            if (b == 1) { budget[at] = 1; at++; continue; } // stays a wide node of its own
+            for (int q = nchild; q > at + 1; q--) child[q] = child[q - 1], budget[q] = budget[q - 1];
+            child[at] = left[id], budget[at] = k;
+            child[at + 1] = right[id], budget[at + 1] = b - k;
+            nchild++; // (sum of budgets <= 8 and every entry holds >= 1: never more than 8 entries)
+        }
+    }
+#endif
+    while (!EGR_SAH_COLLAPSE && nchild < EGR_WIDTH) {
         // Which internal child to open: the largest one whose WHOLE subtree still fits into the free slots (it dissolves into
         // this node instead of becoming an under-filled node of its own: fewer, fuller nodes = fewer 128-B node visits per
         // ray); if none fits, the largest one (keeps the upper levels balanced).
@@ -316,7 +430,7 @@ template <class T> static void dalloc(egr_context *c, T *&p, size_t count) {
 void egr_bvh_free(egr_context *c) {
     egr_dev_free(c, c->wnodes), egr_dev_free(c, c->pos_of_gid), egr_dev_free(c, c->inst_w), egr_dev_free(c, c->inst_m), egr_dev_free(c, c->app), egr_dev_free(c, c->aabb), egr_dev_free(c, c->grad_rows);
     egr_dev_free(c, c->sort_tmp), egr_dev_free(c, c->keys_in), egr_dev_free(c, c->keys_out), egr_dev_free(c, c->vals_in), egr_dev_free(c, c->vals_out);
-    egr_dev_free(c, c->k_left), egr_dev_free(c, c->k_right), egr_dev_free(c, c->k_parent), egr_dev_free(c, c->k_first), egr_dev_free(c, c->k_last), egr_dev_free(c, c->wide_of), egr_dev_free(c, c->scratch_u32), egr_dev_free(c, c->out_of_frame);
+    egr_dev_free(c, c->k_left), egr_dev_free(c, c->k_right), egr_dev_free(c, c->k_parent), egr_dev_free(c, c->k_first), egr_dev_free(c, c->k_last), egr_dev_free(c, c->k_dp), egr_dev_free(c, c->k_flags), egr_dev_free(c, c->wide_of), egr_dev_free(c, c->scratch_u32), egr_dev_free(c, c->out_of_frame);
     c->n_alloc = 0;
     c->n_built = 0;
     c->bvh_valid = false;
@@ -336,6 +450,7 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
     dalloc(c, c->keys_in, cap), dalloc(c, c->keys_out, cap), dalloc(c, c->vals_in, cap), dalloc(c, c->vals_out, cap);
     dalloc(c, c->k_left, cap), dalloc(c, c->k_right, cap), dalloc(c, c->k_parent, 2 * (size_t)cap);
     dalloc(c, c->k_first, cap), dalloc(c, c->k_last, cap), dalloc(c, c->wide_of, cap);
+    dalloc(c, c->k_dp, (size_t)cap * EGR_DP_STRIDE), dalloc(c, c->k_flags, cap);
     if (!c->scratch_u32) dalloc(c, c->scratch_u32, 64);
     if (!c->out_of_frame) {
         dalloc(c, c->out_of_frame, 1);
@@ -408,6 +523,10 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(k_karras, dim3(nblk(n - 1)), dim3(BS), 0, s, (int)n, c->keys_out, c->k_left, c->k_right, c->k_parent, c->k_first,
                            c->k_last);
+#if EGR_SAH_COLLAPSE
+        EGR_HIP(hipMemsetAsync(c->k_flags, 0, (size_t)n * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_sah_bottom_up, dim3(nblk(n)), dim3(BS), 0, s, (int)n, c->k_left, c->k_right, c->k_parent, c->aabb, c->vals_out, c->k_flags, c->k_dp);
+#endif
         // level-by-level collapse; frontiers ping-pong in keys_in (free after the sort)
         uint32_t *fr0 = reinterpret_cast<uint32_t *>(c->keys_in), *fr1 = fr0 + c->n_alloc;
         uint32_t init[4] = {1u, 0u, 0u, 0u}; // wide node 0 = binary root
@@ -419,7 +538,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->level_start = {0, 1};
         while (count > 0) {
             hipLaunchKernelGGL(k_collapse_level, dim3(nblk(count)), dim3(BS), 0, s, (int)n, count, fr0, c->k_left, c->k_right, c->k_first, c->k_last,
-                               c->wide_of, counters, fr1, c->wnodes);
+                               c->wide_of, counters, fr1, c->wnodes, c->k_dp);
             uint32_t hc[2];
             EGR_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
             EGR_HIP(hipStreamSynchronize(s));

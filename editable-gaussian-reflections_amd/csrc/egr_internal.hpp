@@ -102,6 +102,7 @@ struct DeviceView { // everything a kernel needs, passed by value
 };
 
 enum ControlWord : int {
+    CW_ACCEPTED = 0,    // per-step 64-bit counters: accepted candidates = what the reference inserts into its forward list
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
     CW_BUCKET_RECORDS = 7, // gradient records the bounce-step backward added to the gradient rows in this launch
@@ -156,6 +157,8 @@ struct egr_context {
     uint32_t *vals_in = nullptr, *vals_out = nullptr;
     int32_t *k_left = nullptr, *k_right = nullptr, *k_parent = nullptr; // Karras arrays (index space: internal i, leaf n-1+j)
     uint32_t *k_first = nullptr, *k_last = nullptr;
+    float *k_dp = nullptr;       // SAH collapse: [n_alloc][16] box + T(1..7) per binary internal node (bvh.hip: k_sah_bottom_up)
+    uint32_t *k_flags = nullptr; // its arrival counters
     uint32_t *scratch_u32 = nullptr; // bounds (6), depth histogram, cursors
     // launch scratch
     float *cand_keys = nullptr;

@@ -406,11 +406,12 @@ struct Raytracer : torch::CustomClassHolder {
         egr_counters c{};
         check(egr_get_counters(ctx, &c, current_stream()), "get_counters");
         // [rays0..2, candidates0..2, composited0..2, lifetime_rays, lifetime_launches, status, bvh_depth, bucket_records, device_bytes, arena_blocks_used, arena_blocks_cap,
-        //  ext_blocks_used, ext_blocks_cap]
+        //  ext_blocks_used, ext_blocks_cap, accepted0..2]
         return {(int64_t)c.rays[0], (int64_t)c.rays[1], (int64_t)c.rays[2], (int64_t)c.candidates[0], (int64_t)c.candidates[1],
                 (int64_t)c.candidates[2], (int64_t)c.composited[0], (int64_t)c.composited[1], (int64_t)c.composited[2],
                 (int64_t)c.lifetime_rays, (int64_t)c.lifetime_launches, (int64_t)c.status, (int64_t)c.bvh_depth, (int64_t)c.bucket_records,
-                (int64_t)c.device_bytes, (int64_t)c.arena_blocks_used, (int64_t)c.arena_blocks_cap, (int64_t)c.ext_blocks_used, (int64_t)c.ext_blocks_cap};
+                (int64_t)c.device_bytes, (int64_t)c.arena_blocks_used, (int64_t)c.arena_blocks_cap, (int64_t)c.ext_blocks_used, (int64_t)c.ext_blocks_cap,
+                (int64_t)c.accepted[0], (int64_t)c.accepted[1], (int64_t)c.accepted[2]};
     }
     void reset_lifetime_counters() { check(egr_reset_lifetime_counters(ctx, current_stream()), "reset_lifetime_counters"); }
     void enable_timing(bool on) { egr_enable_timing(ctx, on ? 1 : 0); }

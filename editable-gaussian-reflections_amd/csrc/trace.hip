@@ -267,8 +267,8 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
 #endif
 template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(EGR_FWD_WAVES, EGR_FWD_WAVES))) k_forward_chain(DeviceView v) {
 #include "forward_decl.inc"
-    __shared__ uint32_t wc[3 * EGR_NSTEPS]; // this wave's ray / candidate / composited counts per step
-    if (lane < 3 * EGR_NSTEPS) wc[lane] = 0u;
+    __shared__ uint32_t wc[4 * EGR_NSTEPS]; // this wave's ray / candidate / composited / accepted counts per step
+    if (lane < 4 * EGR_NSTEPS) wc[lane] = 0u;
     __syncthreads();
     uint32_t cur_q = blockIdx.x & 7u;
 
@@ -280,7 +280,8 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
                 const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
 #include "forward_task.inc"
                 const uint32_t a = wave_sum_u32(active ? 1u : 0u), b = wave_sum_u32(active ? traversed : 0u), c2 = wave_sum_u32(active ? nhits : 0u);
-                if (lane == 0) wc[3 * step] += a, wc[3 * step + 1] += b, wc[3 * step + 2] += c2;
+                const uint32_t d2 = wave_sum_u32(active ? cnt : 0u);
+                if (lane == 0) wc[4 * step] += a, wc[4 * step + 1] += b, wc[4 * step + 2] += c2, wc[4 * step + 3] += d2;
             } while (false);
             // R4 / R5 of this step for the tile's rays
             const uint32_t etask = v.task_begin + tq;
@@ -289,7 +290,10 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
         }
     }
     __syncthreads();
-    if (lane < EGR_NSTEPS) add64(v.control, CW_RAYS + 2 * lane, wc[3 * lane]), add64(v.control, CW_CAND + 2 * lane, wc[3 * lane + 1]), add64(v.control, CW_COMP + 2 * lane, wc[3 * lane + 2]);
+    if (lane < EGR_NSTEPS) {
+        add64(v.control, CW_RAYS + 2 * lane, wc[4 * lane]), add64(v.control, CW_CAND + 2 * lane, wc[4 * lane + 1]), add64(v.control, CW_COMP + 2 * lane, wc[4 * lane + 2]);
+        add64(v.control, CW_ACCEPTED + 2 * lane, wc[4 * lane + 3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

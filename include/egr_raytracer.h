@@ -109,6 +109,9 @@ typedef struct egr_counters {
                                           * the caller's tensors (parameters, gradients, framebuffer) are not included          */
     uint32_t arena_blocks_used, arena_blocks_cap; /* composited-hit arena (backward capacity): 9-KB blocks the last grad launch took / holds */
     uint32_t ext_blocks_used, ext_blocks_cap;     /* candidate-list extension blocks (forward capacity) the last launch took / holds         */
+    uint64_t accepted[EGR_NUM_STEPS];    /* accepted candidates per step = entries the reference inserts into its forward list
+                                          * (shaders.cu:74; its counter runs on over the three steps, so their SUM must stay below
+                                          * ppll_forward_size upstream - there is no check there)                               */
 } egr_counters;
 
 #define EGR_STATUS_OK 0u

@@ -56,7 +56,7 @@ class _Targets(ctypes.Structure):
 
 _OUT_F64 = ["output_rgb", "output_depth", "output_normal", "output_f0", "output_roughness", "output_transmittance",
             "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final"]
-_OUT_INT = ["random_seeds", "num_traversed", "num_accumulated", "num_composited_all_steps", "effective_steps", "num_composited_per_step"]
+_OUT_INT = ["random_seeds", "num_traversed", "num_accumulated", "num_composited_all_steps", "effective_steps", "num_composited_per_step", "num_depth_ties"]
 _OUT_GRAD = ["dL_drgb", "dL_dnormal", "dL_df0", "dL_droughness", "dL_dopacity", "dL_dscale", "dL_dmean", "dL_drotation",
              "total_weight"]
 
@@ -218,6 +218,7 @@ class Oracle:
         for k in _OUT_INT[1:5]:
             out[k] = np.zeros((H, W), np.int32)
         out["num_composited_per_step"] = np.zeros((NSTEPS, H, W), np.int32)
+        out["num_depth_ties"] = np.zeros((H, W), np.int32)
         n = self.n
         gshape = {"dL_drgb": (n, 3), "dL_dnormal": (n, 3), "dL_df0": (n, 3), "dL_droughness": (n, 1), "dL_dopacity": (n, 1),
                   "dL_dscale": (n, 3), "dL_dmean": (n, 3), "dL_drotation": (n, 4), "total_weight": (n, 1)}

@@ -7,7 +7,12 @@ backward, all-reduce of the launch's [22N] buffer), scale decay + Adam + clamps 
 `prune_points(total_weight / interval < min_weight)`, `total_weight.zero_()`, `rebuild_bvh()` BEFORE the optimizer step
 (train.py:238-247); in the middle of an interval far-field points are appended and the tracer resized (train.py:256-260).
 Every rank also runs the same loop on an UNPARTITIONED tracer and compares, iteration by iteration: gradients, total_weight,
-the prune mask, the parameters. Prints CONFIG4_OK on rank 0."""
+the prune mask, the parameters - and on a SECOND unpartitioned tracer (`twin`), because a training loop is not reproducible to the
+last bit even on one GPU: float atomics add a gaussian's contributions in varying order, and Adam with eps = 1e-15 (gaussian_model.py:338)
+turns a gradient element whose sign depends on that order - a sum that cancels to ~0 - into an update of +-lr; from the second
+iteration on a few dozen of the 6.6M parameter elements differ by up to 2 lr between ANY two runs, and the gaussians they belong to
+render slightly differently. The bar for the partitioned run is therefore: bit-level agreement where that is defined (iteration 1,
+the prune masks), and no further from the single-rank run than the single-rank run is from its own twin. Prints CONFIG4_OK on rank 0."""
 import importlib
 import math
 import os
@@ -51,7 +56,7 @@ class Run:
         self.m.get_metadata().total_num_calls.zero_()
 
 
-part, full = Run(True), Run(False)
+part, full, twin = Run(True), Run(False), Run(False)
 assert part.m.get_gaussians().grad_delta.numel() == 22 * N and full.m.get_gaussians().grad_delta.numel() == 0
 
 
@@ -68,16 +73,17 @@ def outliers(a, b, tol=1e-5):
 log = []
 for it in range(1, ITERS + 1):
     cam = cams[(it - 1) % len(cams)]
-    for r in (part, full):
+    for r in (part, full, twin):
         r.step.update_learning_rate(it)
         ren.render(cam, r.rt)
     torch.cuda.synchronize()
-    gp, gf = part.m.get_gaussians(), full.m.get_gaussians()
+    gp, gf, gt = part.m.get_gaussians(), full.m.get_gaussians(), twin.m.get_gaussians()
     n = gf.mean.shape[0]
-    assert gp.mean.shape[0] == n
+    assert gp.mean.shape[0] == n and gt.mean.shape[0] == n
     e_grad = rel(gp.grad_flat[: 21 * n], gf.grad_flat[: 21 * n])
     e_w = rel(gp.grad_flat[21 * n:], gf.grad_flat[21 * n:])
     w_out = outliers(gp.total_weight, gf.total_weight)
+    e_grad_twin, w_out_twin = rel(gt.grad_flat[: 21 * n], gf.grad_flat[: 21 * n]), outliers(gt.total_weight, gf.total_weight)
     assert part.m.get_counters()[11] == 0 and full.m.get_counters()[11] == 0, (it, part.m.get_counters()[11], full.m.get_counters()[11])
     assert float(gp.grad_delta.abs().max()) == 0.0
     pruned = 0
@@ -87,17 +93,17 @@ for it in range(1, ITERS + 1):
         while int(((wf - float(t)).abs() < 1e-4 * float(t)).sum()) > 0:  # a threshold no gaussian sits on (float-atomic noise is ~1e-6 of a weight)
             t *= 1.001
         dist.broadcast(t, 0)
-        masks = [(r.m.get_gaussians().total_weight / INTERVAL < float(t)).squeeze(1) for r in (part, full)]
-        assert int((masks[0] != masks[1]).sum()) == 0, (it, int((masks[0] != masks[1]).sum()))
+        masks = [(r.m.get_gaussians().total_weight / INTERVAL < float(t)).squeeze(1) for r in (part, full, twin)]
+        assert int((masks[0] != masks[1]).sum()) == 0 and int((masks[2] != masks[1]).sum()) == 0, (it, int((masks[0] != masks[1]).sum()), int((masks[2] != masks[1]).sum()))
         pruned = int(masks[1].sum())
         assert 0 < pruned < n // 2, pruned
-        for r, mask in zip((part, full), masks):
+        for r, mask in zip((part, full, twin), masks):
             r.pc.prune_points(mask)
             r.step.prune(~mask)
             r.m.get_gaussians().total_weight.zero_()
             r.rt.rebuild_bvh()
             assert r.m.get_gaussians().mean.shape[0] == n - pruned and r.m.check_bvh() == 0
-    for r in (part, full):
+    for r in (part, full, twin):
         r.step.step()
     if it == FARFIELD_AT:  # train.py:256-260 / gaussian_model.py:233-283, mid-interval: total_weight of the existing rows must survive the resize
         rng = np.random.default_rng(5)
@@ -107,7 +113,7 @@ for it in range(1, ITERS + 1):
         new = dict(mean=xyz, scale=torch.log(torch.sqrt(d2) * 0.1)[:, None].repeat(1, 3).cpu().numpy(), rotation=np.tile(np.array([[1, 0, 0, 0]], np.float32), (len(xyz), 1)),
                    opacity=np.full((len(xyz), 1), math.log(0.1 / 0.9), np.float32), rgb=np.full((len(xyz), 3), 0.2, np.float32), normal=np.zeros((len(xyz), 3), np.float32),
                    f0=np.full((len(xyz), 3), 0.04, np.float32), roughness=np.zeros((len(xyz), 1), np.float32))
-        for r in (part, full):
+        for r in (part, full, twin):
             before = r.m.get_gaussians().total_weight.clone()
             r.pc.append_points(new)
             r.step.extend(len(xyz))
@@ -116,26 +122,28 @@ for it in range(1, ITERS + 1):
             assert tw.shape[0] == before.shape[0] + len(xyz) and torch.equal(tw[: before.shape[0]], before) and float(tw[before.shape[0]:].abs().max()) == 0.0
     torch.cuda.synchronize()
     n2 = full.pc._xyz.shape[0]
-    assert part.pc._xyz.shape[0] == n2
+    assert part.pc._xyz.shape[0] == n2 and twin.pc._xyz.shape[0] == n2
     p_out = sum(outliers(a, b) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
+    p_out_twin = sum(outliers(a, b) for a, b in zip(twin.pc.parameters(), full.pc.parameters()))
     p_rel = max(rel(a, b) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
-    log.append(dict(it=it, n=n, grad=e_grad, weight=e_w, weight_outliers=w_out, pruned=pruned, param_outliers=p_out, param_worst=p_rel))
+    log.append(dict(it=it, n=n, grad=e_grad, grad_twin=e_grad_twin, weight=e_w, weight_outliers=w_out, weight_outliers_twin=w_out_twin, pruned=pruned,
+                    param_outliers=p_out, param_outliers_twin=p_out_twin, param_worst=p_rel))
     if rank == 0:
         print("CONFIG4", log[-1], flush=True)
-    # the launch's gradients: what the partition + all-reduce must reproduce. Relative to the tensor maximum they carry float-atomic
-    # reordering noise only - as long as both runs trace the same parameters (iteration 1) - plus, later, what a few +-lr outliers change
-    assert e_grad < (1e-5 if it == 1 else 1e-3) and (e_w < 1e-5 or w_out <= 1e-4 * n), log[-1]
-    assert p_out <= 2e-5 * 21 * n2 * it, log[-1]  # (measured: a handful of elements per iteration out of 21 N)
+    if it == 1:  # identical parameters on all three runs: the partition + all-reduce reproduces the single-rank launch to float-atomic reordering
+        assert e_grad < 1e-5 and e_w < 1e-5 and w_out == 0, log[-1]
+    # later: as close to the single-rank run as its own twin is (x3 + a floor: the counts are small numbers)
+    assert e_grad <= max(3.0 * e_grad_twin, 1e-5) and w_out <= 3 * w_out_twin + 20 and p_out <= 3 * p_out_twin + 50, log[-1]
     lr_max = max(LRS.values())
     assert p_rel * max(float(b.abs().max()) for b in full.pc.parameters()) <= 4.0 * lr_max * it + 1e-6, log[-1]  # nothing beyond what Adam can move
 
 with torch.no_grad():  # evaluation render of the partitioned tracer: whole image on every rank
-    for r in (part, full):
+    for r in (part, full, twin):
         r.m.get_metadata().total_num_calls.zero_()
         r.rt(cams[0])
-ip, iff = part.m.get_framebuffer().output_final, full.m.get_framebuffer().output_final
-mse = float(((ip - iff) ** 2).mean())
-assert part.m.get_counters()[0] == W * H and (mse == 0.0 or 10 * math.log10(1.0 / mse) > 60.0), mse
+ip, iff, itw = part.m.get_framebuffer().output_final, full.m.get_framebuffer().output_final, twin.m.get_framebuffer().output_final
+mse, mse_twin = float(((ip - iff) ** 2).mean()), float(((itw - iff) ** 2).mean())
+assert part.m.get_counters()[0] == W * H and mse <= max(4.0 * mse_twin, 1e-7), (mse, mse_twin)
 dist.barrier()
 if rank == 0:
     print("CONFIG4_OK", log[-1], flush=True)

@@ -96,7 +96,10 @@ def grads_vs_oracle_listing_flipped_pixels(ren, rt, o, camera, tg, W, H, name, m
     the clip sphere) more or less; on a small image one such hit is 1-2e-3 of a tensor's maximum. Instead of loosening the bar:
       1. one grad launch on both sides -> nine gradient tensors; if all are < bar, done;
       2. otherwise LIST the pixels whose rays differ: composited hits per bounce step (HIP: egr_debug_get_step_hits, oracle:
-         num_hits[step]) or total transmittance of a step (a flipped candidate behind the last composited hit only shows there);
+         num_hits[step]), total transmittance of a step (a flipped candidate behind the last composited hit only shows there), or two
+         consecutive composited hits within 4 ulps of each other in the oracle (their ORDER - hence their two weights - is decided by
+         the last bits of t, where this build contracts fmas and the oracle does not; exact ties: by the list order, which is
+         unspecified upstream);
       3. assert there are at most `max_flipped` of them, take their 16x16 macro tiles out ON BOTH SIDES (HIP: the product's own tile
          partition, one rank per macro tile; oracle: pixel mask) and assert < bar on everything else.
     Returns (per-tensor errors over all pixels, per-tensor errors without the listed pixels, listed pixels)."""
@@ -123,12 +126,14 @@ def grads_vs_oracle_listing_flipped_pixels(ren, rt, o, camera, tg, W, H, name, m
     o.total_num_calls = k - 1
     img_o = o.raytrace(False)
     tt_h = hip_outputs(rt)["output_total_transmittance"][..., 0]
-    flipped = np.any(hits_h != hits_o, axis=0) | np.any(np.abs(tt_h - img_o["output_total_transmittance"][..., 0]) > 2e-5, axis=0)
+    why = {"hits": np.any(hits_h != hits_o, axis=0), "T_total": np.any(np.abs(tt_h - img_o["output_total_transmittance"][..., 0]) > 2e-5, axis=0),
+           "near_tie": ref["num_depth_ties"] > 0}
+    flipped = why["hits"] | why["T_total"] | why["near_tie"]
     ys, xs = np.nonzero(flipped)
-    listing = [(int(x), int(y), hits_h[:, y, x].tolist(), hits_o[:, y, x].tolist()) for y, x in zip(ys, xs)]
+    listing = [(int(x), int(y), "+".join(k for k in why if why[k][y, x]), hits_h[:, y, x].tolist(), hits_o[:, y, x].tolist()) for y, x in zip(ys, xs)]
     assert 0 < len(listing) <= max_flipped, (name, err_all, listing[:20], len(listing))
     mtx, mty = (W + 15) // 16, (H + 15) // 16
-    bad_tiles = sorted({(y // 16) * mtx + (x // 16) for x, y, _, _ in listing})
+    bad_tiles = sorted({(y // 16) * mtx + (x // 16) for x, y, *_ in listing})
     yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     keep = ~np.isin((yy // 16) * mtx + (xx // 16), bad_tiles)
     o.set_pixel_mask(keep)

@@ -4,7 +4,7 @@ TAG=$1; shift
 mkdir -p gpurun_out/$TAG
 for CFG in "$@"; do
   NAME=$(echo "$CFG" | tr ' =' '__')
-  touch editable-gaussian-reflections_amd/csrc/trace.hip
+  touch editable-gaussian-reflections_amd/csrc/trace.hip editable-gaussian-reflections_amd/csrc/bvh.hip
   env $CFG python -c "import importlib; importlib.import_module('editable-gaussian-reflections_amd.build').build_all()" > gpurun_out/$TAG/build_$NAME.log 2>&1 || { echo "$CFG: BUILD FAILED"; tail -5 gpurun_out/$TAG/build_$NAME.log; continue; }
   env $CFG python bench.py --no-cpu-baseline --steps 60 --warmup 40 ${SWEEP_ARGS:---no-second-variant} > gpurun_out/$TAG/bench_$NAME.json 2> gpurun_out/$TAG/bench_$NAME.err
   python - <<PY
