@@ -36,6 +36,12 @@
 #ifndef EGR_GPOP
 #define EGR_GPOP 4 // nodes a lane group pops per iteration of the group walk
 #endif
+#ifndef EGR_PAIR_WALK
+#define EGR_PAIR_WALK 1 // bounce steps: wave-wide (ray, node) pair stack + one lane per (ray, leaf) pair (0: round 2's per-ray stacks and two-phase group walk)
+#endif
+#ifndef EGR_PSTK
+#define EGR_PSTK 512 // pair-stack entries kept in LDS
+#endif
 
 namespace {
 

@@ -84,6 +84,7 @@ for it in range(1, ITERS + 1):
     e_w = rel(gp.grad_flat[21 * n:], gf.grad_flat[21 * n:])
     w_out = outliers(gp.total_weight, gf.total_weight)
     e_grad_twin, w_out_twin = rel(gt.grad_flat[: 21 * n], gf.grad_flat[: 21 * n]), outliers(gt.total_weight, gf.total_weight)
+    g_out, g_out_twin = outliers(gp.grad_flat[: 21 * n], gf.grad_flat[: 21 * n]), outliers(gt.grad_flat[: 21 * n], gf.grad_flat[: 21 * n])
     assert part.m.get_counters()[11] == 0 and full.m.get_counters()[11] == 0, (it, part.m.get_counters()[11], full.m.get_counters()[11])
     assert float(gp.grad_delta.abs().max()) == 0.0
     pruned = 0
@@ -126,14 +127,15 @@ for it in range(1, ITERS + 1):
     p_out = sum(outliers(a, b) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
     p_out_twin = sum(outliers(a, b) for a, b in zip(twin.pc.parameters(), full.pc.parameters()))
     p_rel = max(rel(a, b) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
-    log.append(dict(it=it, n=n, grad=e_grad, grad_twin=e_grad_twin, weight=e_w, weight_outliers=w_out, weight_outliers_twin=w_out_twin, pruned=pruned,
+    log.append(dict(it=it, n=n, grad=e_grad, grad_twin=e_grad_twin, grad_outliers=g_out, grad_outliers_twin=g_out_twin, weight=e_w, weight_outliers=w_out, weight_outliers_twin=w_out_twin, pruned=pruned,
                     param_outliers=p_out, param_outliers_twin=p_out_twin, param_worst=p_rel))
     if rank == 0:
         print("CONFIG4", log[-1], flush=True)
     if it == 1:  # identical parameters on all three runs: the partition + all-reduce reproduces the single-rank launch to float-atomic reordering
         assert e_grad < 1e-5 and e_w < 1e-5 and w_out == 0, log[-1]
-    # later: as close to the single-rank run as its own twin is (x3 + a floor: the counts are small numbers)
-    assert e_grad <= max(3.0 * e_grad_twin, 1e-5) and w_out <= 3 * w_out_twin + 20 and p_out <= 3 * p_out_twin + 50, log[-1]
+    # later: as close to the single-rank run as its own twin is - counted in elements further apart than 1e-5 of the tensor maximum
+    # (x3 + a floor: the counts are small numbers; the maximum itself is one outlier's size and fluctuates between 1e-5 and 1e-2)
+    assert g_out <= 3 * g_out_twin + 50 and w_out <= 3 * w_out_twin + 20 and p_out <= 3 * p_out_twin + 50 and e_grad < 2e-2, log[-1]
     lr_max = max(LRS.values())
     assert p_rel * max(float(b.abs().max()) for b in full.pc.parameters()) <= 4.0 * lr_max * it + 1e-6, log[-1]  # nothing beyond what Adam can move
 
