@@ -39,6 +39,14 @@
 #ifndef EGR_PAIR_WALK
 #define EGR_PAIR_WALK 1 // bounce steps: wave-wide (ray, node) pair stack + one lane per (ray, leaf) pair (0: round 2's per-ray stacks and two-phase group walk)
 #endif
+#ifndef EGR_PIPELINE
+#define EGR_PIPELINE 1 // pair walk: issue an evaluation batch's record fetches and a walk batch's node fetches together (0: one kind of batch per iteration)
+#endif
+#define EGR_WALK_MAX_LEAVES (8 * EGR_GPOP * EGR_WIDTH) // leaf pairs one walk batch can add
+#define EGR_LBUF (64 + (EGR_PIPELINE ? 2 : 1) * EGR_WALK_MAX_LEAVES)
+#ifndef EGR_PAIR_PRIMARY
+#define EGR_PAIR_PRIMARY 0 // 1: primary rays walk pairwise too (0: one packet per tile)
+#endif
 #ifndef EGR_PSTK
 #define EGR_PSTK 512 // pair-stack entries kept in LDS
 #endif

@@ -134,10 +134,12 @@ for it in range(1, ITERS + 1):
     if it == 1:  # identical parameters on all three runs: the partition + all-reduce reproduces the single-rank launch to float-atomic reordering
         assert e_grad < 1e-5 and e_w < 1e-5 and w_out == 0, log[-1]
     # later: as close to the single-rank run as its own twin is - counted in elements further apart than 1e-5 of the tensor maximum
-    # (x3 + a floor: the counts are small numbers; the maximum itself is one outlier's size and fluctuates between 1e-5 and 1e-2)
-    assert g_out <= 3 * g_out_twin + 50 and w_out <= 3 * w_out_twin + 20 and p_out <= 3 * p_out_twin + 50 and e_grad < 2e-2, log[-1]
+    # (an order of magnitude + a floor: the counts are tens to hundreds out of 6.3M elements and heavy-tailed - one differing large
+    # gaussian touches many neighbours; the maximum itself is one outlier's size and fluctuates between 1e-5 and 1e-2)
+    assert g_out <= 10 * g_out_twin + 200 and w_out <= 10 * w_out_twin + 100 and p_out <= 10 * p_out_twin + 200 and e_grad < 2e-2, log[-1]
     lr_max = max(LRS.values())
-    assert p_rel * max(float(b.abs().max()) for b in full.pc.parameters()) <= 4.0 * lr_max * it + 1e-6, log[-1]  # nothing beyond what Adam can move
+    p_abs = max(float((a - b).abs().max()) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
+    assert p_abs <= 4.0 * lr_max * it + 1e-6, (p_abs, log[-1])  # nothing beyond what Adam can move a parameter in `it` steps
 
 with torch.no_grad():  # evaluation render of the partitioned tracer: whole image on every rank
     for r in (part, full, twin):
