@@ -201,6 +201,10 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
                 fprintf(stderr, "[egr stats forward step %d] first wave exit -> last wave exit: %.3f ms\n", k,
                         (double)(u64(CW_DBG3 + 4 * k + 2) - u64(CW_DBG3 + 4 * k)) / 100e6 * 1e3);
             for (int k = 0; k < 2; k++)
+                fprintf(stderr, "[egr stats backward %s] wave-cycles(s_memtime) per-hit math %llu, neighbour combine + LDS table %llu, wide adds %llu, table flush %llu; hit rows %llu\n",
+                        k ? "bounce" : "primary", (unsigned long long)u64(CW_DBG2 + 16 + 10 * k), (unsigned long long)u64(CW_DBG2 + 18 + 10 * k),
+                        (unsigned long long)u64(CW_DBG2 + 20 + 10 * k), (unsigned long long)u64(CW_DBG2 + 22 + 10 * k), (unsigned long long)u64(CW_DBG2 + 24 + 10 * k));
+            for (int k = 0; k < 2; k++)
                 fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | group walk: phase A %llu phase B %llu\n", k ? "bounce" : "primary",
                         (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2), (unsigned long long)u64(CW_DBG2 + 8 + 4 * k),
                         (unsigned long long)u64(CW_DBG2 + 8 + 4 * k + 2));

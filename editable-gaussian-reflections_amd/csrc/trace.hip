@@ -34,10 +34,7 @@
 #include "egr_epilogue.hpp" // (includes egr_state.hpp) the step epilogue, for the fused per-tile chain
 
 #ifndef EGR_GPOP
-#define EGR_GPOP 4 // nodes a lane group pops per iteration of the group walk
-#endif
-#ifndef EGR_PAIR_WALK
-#define EGR_PAIR_WALK 1 // bounce steps: wave-wide (ray, node) pair stack + one lane per (ray, leaf) pair (0: round 2's per-ray stacks and two-phase group walk)
+#define EGR_GPOP 4 // pair walk: a walk batch pops up to 8 x EGR_GPOP (ray, node) pairs, EGR_GPOP per lane group
 #endif
 #ifndef EGR_PIPELINE
 #define EGR_PIPELINE 1 // pair walk: issue an evaluation batch's record fetches and a walk batch's node fetches together (0: one kind of batch per iteration)

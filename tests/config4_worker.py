@@ -95,10 +95,22 @@ for it in range(1, ITERS + 1):
             t *= 1.001
         dist.broadcast(t, 0)
         masks = [(r.m.get_gaussians().total_weight / INTERVAL < float(t)).squeeze(1) for r in (part, full, twin)]
-        assert int((masks[0] != masks[1]).sum()) == 0 and int((masks[2] != masks[1]).sum()) == 0, (it, int((masks[0] != masks[1]).sum()), int((masks[2] != masks[1]).sum()))
+        # by now the three runs hold slightly different parameters (see the header), so a gaussian whose weight sits within that noise of
+        # the threshold may fall on either side: the partitioned run may disagree with the single-rank run on no more gaussians than
+        # its twin does (+ a handful); all three then prune the single-rank run's mask so that they stay comparable row by row
+        mism, mism_twin = int((masks[0] != masks[1]).sum()), int((masks[2] != masks[1]).sum())
+        assert mism <= 3 * mism_twin + 5, (it, mism, mism_twin)
+        # (a real multi-GPU run prunes by `part`'s mask, identical on every rank because the all-reduced total_weight is; the reference
+        # run of THIS test lives once per process and each copy carries its own noise, so rank 0's mask is the one everybody applies)
+        pm = [masks[0].cpu().clone() for _ in range(world)]
+        dist.all_gather(pm, masks[0].cpu())
+        assert all(torch.equal(pm[0], x) for x in pm), "the partitioned runs of the two ranks disagree on the prune mask"
+        ref_mask = masks[1].cpu()
+        dist.broadcast(ref_mask, 0)
+        masks[1] = ref_mask.cuda()
         pruned = int(masks[1].sum())
         assert 0 < pruned < n // 2, pruned
-        for r, mask in zip((part, full, twin), masks):
+        for r, mask in zip((part, full, twin), (masks[1], masks[1], masks[1])):
             r.pc.prune_points(mask)
             r.step.prune(~mask)
             r.m.get_gaussians().total_weight.zero_()
@@ -127,7 +139,7 @@ for it in range(1, ITERS + 1):
     p_out = sum(outliers(a, b) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
     p_out_twin = sum(outliers(a, b) for a, b in zip(twin.pc.parameters(), full.pc.parameters()))
     p_rel = max(rel(a, b) for a, b in zip(part.pc.parameters(), full.pc.parameters()))
-    log.append(dict(it=it, n=n, grad=e_grad, grad_twin=e_grad_twin, grad_outliers=g_out, grad_outliers_twin=g_out_twin, weight=e_w, weight_outliers=w_out, weight_outliers_twin=w_out_twin, pruned=pruned,
+    log.append(dict(it=it, n=n, mask_mismatch=(mism, mism_twin) if it % INTERVAL == 0 else None, grad=e_grad, grad_twin=e_grad_twin, grad_outliers=g_out, grad_outliers_twin=g_out_twin, weight=e_w, weight_outliers=w_out, weight_outliers_twin=w_out_twin, pruned=pruned,
                     param_outliers=p_out, param_outliers_twin=p_out_twin, param_worst=p_rel))
     if rank == 0:
         print("CONFIG4", log[-1], flush=True)
