@@ -17,10 +17,9 @@
 #define EGR_LEAF_FLAG 0x80000000u  // child slot link: leaf -> EGR_LEAF_FLAG | record index, internal -> child node index
 #define EGR_EMPTY_SLOT 0xFFFFFFFFu // unused child slot (checked before the leaf flag)
 #define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
-#define EGR_LSTK 24                // per-lane traversal stack entries kept in LDS ...
 #define EGR_MAX_STRANDS 4
 #define EGR_QUEUE_WORDS 16u          // task queue heads per strand: 2 kernels (forward chain, backward chain) x 8 XCD heads
-#define EGR_GSTK 232               // ... and spilled to a per-wave global column beyond that
+#define EGR_GSTK 232               // x 64 = entries of a resident wave's global spill column for its (ray, node) pair stack (the first EGR_PSTK live in LDS)
 #define EGR_EXT_BLOCK 16384u // entries of one candidate-list extension block
 #define EGR_EXT_NONE 0xFFFFFFFFu
 #define EGR_HIT_BLOCK_ROWS 8  // composited-hit arena block: 8 rows x 64 lanes x 16 B (+1 header row)
@@ -80,8 +79,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     // per-launch scratch
     float *cand_keys;      // [slots][cand_cap][64]
     float2 *cand_vals;     // [slots][cand_cap][64]  (alpha, gaussian id bits)
-    uint32_t *cand_queue;  // [slots][cand_cap][64]  leaf record indices awaiting evaluation (group walk: phase A fills, phase B drains)
-    uint32_t *stack_spill; // [slots][EGR_GSTK][64] traversal stack entries beyond the LDS part
+    uint32_t *stack_spill; // [slots][EGR_GSTK * 64] pair-stack entries beyond the LDS part (one column per resident wave)
     uint32_t cand_cap;
     // candidate lists longer than cand_cap continue in an extension block (one per ray, EGR_EXT_BLOCK entries, bump-allocated per
     // launch): the reference's candidate pool is global, a single grazing ray may take thousands of entries
@@ -163,7 +161,7 @@ struct egr_context {
     // launch scratch
     float *cand_keys = nullptr;
     float2 *cand_vals = nullptr;
-    uint32_t *cand_queue = nullptr, *stack_spill = nullptr;
+    uint32_t *stack_spill = nullptr;
     bool exact_stats = false;     // egr_set_exact_stats: cube boxes + reference-defined candidate count (takes effect at the next update / rebuild)
     bool boxes_are_cubes = false; // what the current tree was refitted with
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final

@@ -557,7 +557,7 @@ void egr_build_task_order(egr_context *c) {
 void egr_trace_free(egr_context *c) {
     for (auto &o : c->task_orders) egr_dev_free(c, o.table);
     c->task_orders.clear(), c->task_macro = nullptr;
-    egr_dev_free(c, c->stack_spill), egr_dev_free(c, c->cand_keys), egr_dev_free(c, c->cand_vals), egr_dev_free(c, c->cand_queue), egr_dev_free(c, c->hit_arena), egr_dev_free(c, c->task_last_block), egr_dev_free(c, c->state), egr_dev_free(c, c->control), egr_dev_free(c, c->queues), egr_dev_free(c, c->denoise_tmp), egr_dev_free(c, c->ext_keys), egr_dev_free(c, c->ext_vals);
+    egr_dev_free(c, c->stack_spill), egr_dev_free(c, c->cand_keys), egr_dev_free(c, c->cand_vals), egr_dev_free(c, c->hit_arena), egr_dev_free(c, c->task_last_block), egr_dev_free(c, c->state), egr_dev_free(c, c->control), egr_dev_free(c, c->queues), egr_dev_free(c, c->denoise_tmp), egr_dev_free(c, c->ext_keys), egr_dev_free(c, c->ext_vals);
     for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -581,13 +581,13 @@ void egr_trace_alloc(egr_context *c) {
     uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
     // forward budget: the reference's ppll_forward_size entries x 36 B, spent on (key 4 B + value 8 B) x 64 lanes x cap per slot
+    // (the leaf pairs awaiting evaluation live in LDS since the pair walk: no queue in global memory)
     double fwd_bytes = (double)c->fwd_capacity * 36.0;
     const size_t S = (size_t)c->strands; // every strand owns a full set of resident-wave scratch slots
-    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * (double)S * EGR_WAVE * 16.0)); // key 4 + value 8 + queue 4 bytes
+    uint64_t cap = (uint64_t)(fwd_bytes / ((double)c->num_slots * (double)S * EGR_WAVE * 12.0)); // key 4 + value 8 bytes
     c->cand_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 64), 16384) & ~7u;
     egr_dev_alloc_raw(c, (void **)&c->cand_keys, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float));
     egr_dev_alloc_raw(c, (void **)&c->cand_vals, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(float2));
-    egr_dev_alloc_raw(c, (void **)&c->cand_queue, S * c->num_slots * c->cand_cap * EGR_WAVE * sizeof(uint32_t));
     // extension blocks: 1/8 of the forward byte budget on top (12 B per entry), at least 64 blocks
     c->ext_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(fwd_bytes / 8.0 / (12.0 * EGR_EXT_BLOCK)), 64), 65536);
     egr_dev_alloc_raw(c, (void **)&c->ext_keys, (size_t)c->ext_blocks_cap * EGR_EXT_BLOCK * sizeof(float));
@@ -629,7 +629,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
-    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_queue = c->cand_queue, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
+    v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.ext_keys = c->ext_keys, v.ext_vals = c->ext_vals, v.ext_blocks_cap = c->ext_blocks_cap;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
@@ -666,7 +666,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
             w.task_count = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)(st + 1)) / (uint64_t)S) - w.task_begin;
             w.queues = c->queues + EGR_QUEUE_WORDS * st;
             const size_t slot0 = (size_t)st * c->num_slots;
-            w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE, w.cand_queue += slot0 * c->cand_cap * EGR_WAVE;
+            w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE;
             w.stack_spill += slot0 * EGR_GSTK * EGR_WAVE;
             const dim3 sgrid(std::max(1u, std::min(c->num_slots, w.task_count)));
             egr_stamp_begin(c, "forward_chain", ls);

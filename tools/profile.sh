@@ -8,8 +8,12 @@ set -u
 TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --strands 1 --steps 20 --warmup 50 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
-grep -a "^{" $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
+# one process per opacity variant, so that a kernel's average in the stats file belongs to ONE workload (the headline line first)
+for VAR in init trained; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$VAR -o t -- python bench.py --strands 1 --steps 20 --warmup 50 --no-cpu-baseline --no-second-variant --variant $VAR > $OUT/bench_under_rocprof_$VAR.log 2>&1
+  grep -a "^{" $OUT/bench_under_rocprof_$VAR.log | tail -1 > $OUT/bench_line_under_rocprof_$VAR.json
+  find $OUT/trace_$VAR -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_$VAR.csv \;
+done
 pass() { # workload-config workload-variant index counters...
   local CFG=$1 VAR=$2 IDX=$3; shift 3
   ( time PMC_CONFIG=$CFG PMC_VARIANT=$VAR EGR_STRANDS=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${CFG}_${VAR}_$IDX -o p -- python tools/pmc_run.py ) > $OUT/pmc_${CFG}_${VAR}_$IDX.log 2>&1
@@ -27,5 +31,4 @@ pass C trained 4 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
 pass C trained 5 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 pass C trained 6 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU
 python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json
-cp $OUT/trace/*/t_kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv 2>/dev/null || find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats.csv \;
 ls -la $OUT | head -40
