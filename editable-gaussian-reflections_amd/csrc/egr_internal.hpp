@@ -59,8 +59,10 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t num_nodes;  // wide nodes (0 if n == 0)
     // partition
     int rank, world;
-    uint32_t num_tasks;  // wave tiles owned by this rank
-    const uint32_t *task_macro; // [num_tasks/4] macro tile index of each group of 4 tasks
+    uint32_t num_tasks;  // tasks (one wave each) of this rank = its macro tiles x (256 / rays_per_task)
+    uint32_t rays_per_task;   // 64: 8x8-pixel tasks (default); 32: 8x4; 16: 4x4 (under-filled ranks of a multi-GPU partition: egr_make_view)
+    uint32_t task_shift;      // log2(tasks per 16x16 macro tile) = 2 / 3 / 4
+    const uint32_t *task_macro; // [num_tasks >> task_shift] macro tile index of each group of tasks
     egr_gaussians g;
     egr_config cfg;
     egr_camera cam;
@@ -182,7 +184,8 @@ struct egr_context {
     uint32_t *task_last_block = nullptr;
     float *state = nullptr;
     uint32_t state_stride = 0;
-    uint32_t num_tasks_total = 0; // wave tiles in the whole image
+    uint32_t num_tasks_total = 0; // 8x8 wave tiles in the whole image (a 16x16 macro tile = 4 of them = 256 rays of ray state)
+    int rays_per_task = 0;        // 0: automatic (64; 32 for a rank of a partition with fewer than two 8x8 tiles per wave slot); env EGR_RAYS_PER_TASK
     uint32_t *task_macro = nullptr; // device table of the current partition's tile order: one of task_orders[].table
     struct TaskOrder {              // tile orders built so far (a partitioned trainer flips between (rank, world) for training launches and
         int rank, world;            // (0, 1) for evaluation renders: egr_set_partition then only swaps a pointer, no sync, no upload)

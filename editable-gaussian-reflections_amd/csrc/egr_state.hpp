@@ -28,21 +28,31 @@ struct TaskGeom {
     uint32_t pixel_id;
     bool inside;
 };
-// task -> wave tile -> pixel. Tasks enumerate the 16x16 macro tiles owned by this rank (every world-th tile), 4 wave
-// tiles each, in the order of v.task_macro: the task range is cut into 8 contiguous chunks (one per XCD queue), each
-// chunk is a compact 2-D block of the image walked along a Z-curve, so the waves resident on one XCD at any time
-// cover a compact patch (their rays meet the same BVH nodes / records -> per-XCD L2 hits, not fabric traffic).
+// task -> pixels. Tasks enumerate the 16x16 macro tiles owned by this rank (every world-th tile) in the order of v.task_macro:
+// the task range is cut into 8 contiguous chunks (one per XCD queue), each chunk is a compact 2-D block of the image walked
+// along a Z-curve, so the waves resident on one XCD at any time cover a compact patch (their rays meet the same BVH nodes /
+// records -> per-XCD L2 hits, not fabric traffic). A macro tile holds 4 tasks of 8x8 pixels (one lane per ray, the default),
+// or 8 of 8x4 / 16 of 4x4 with the upper lanes idle in the per-ray phases: a rank of a multi-GPU partition owns about as many 8x8
+// tiles as there are wave slots, so its launch lasts as long as its heaviest tile - smaller tasks cut that tail, and the pair
+// walk keeps all 64 lanes busy whatever the number of rays (trace.hip: egr_make_view chooses).
 EGR_DI TaskGeom task_geom(const DeviceView &v, uint32_t task, int lane) {
-    uint32_t mtx = (uint32_t)(v.width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
-    uint32_t m = v.task_macro[task >> 2]; // this rank's macro tiles in cache-friendly order (see egr_build_task_order)
-    uint32_t sub = task & 3u;
-    int tx = (int)(m % mtx) * 2 + (int)(sub & 1u), ty = (int)(m / mtx) * 2 + (int)(sub >> 1);
+    const uint32_t mtx = (uint32_t)(v.width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
+    const uint32_t m = v.task_macro[task >> v.task_shift]; // this rank's macro tiles in cache-friendly order (see egr_build_task_order)
+    const uint32_t sub = task & ((1u << v.task_shift) - 1u);
+    const int x0 = (int)(m % mtx) * EGR_MACRO_TILE, y0 = (int)(m / mtx) * EGR_MACRO_TILE;
     TaskGeom g;
-    g.px = tx * EGR_TILE + (lane & 7);
-    g.py = ty * EGR_TILE + (lane >> 3);
-    g.inside = g.px < v.width && g.py < v.height;
+    if (v.task_shift == 2u) { // 2 x 2 tasks of 8 x 8
+        g.px = x0 + (int)(sub & 1u) * 8 + (lane & 7), g.py = y0 + (int)(sub >> 1) * 8 + (lane >> 3);
+    } else if (v.task_shift == 3u) { // 2 x 4 tasks of 8 x 4
+        g.px = x0 + (int)(sub & 1u) * 8 + (lane & 7), g.py = y0 + (int)(sub >> 1) * 4 + ((lane >> 3) & 3);
+    } else { // 4 x 4 tasks of 4 x 4
+        g.px = x0 + (int)(sub & 3u) * 4 + (lane & 3), g.py = y0 + (int)(sub >> 2) * 4 + ((lane >> 2) & 3);
+    }
+    g.inside = (uint32_t)lane < v.rays_per_task && g.px < v.width && g.py < v.height;
     g.pixel_id = (uint32_t)g.py * (uint32_t)v.width + (uint32_t)g.px;
     return g;
 }
+// ray state of (task, lane): task-linear, rays_per_task entries per task (lanes beyond that own no ray and must not touch it)
+EGR_DI StateRef state_of(const DeviceView &v, uint32_t task, int lane) { return StateRef{v.state, v.state_stride, task * v.rays_per_task + (uint32_t)lane}; }
 
 } // namespace

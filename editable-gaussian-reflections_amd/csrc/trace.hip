@@ -297,7 +297,7 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
             // R4 / R5 of this step for the tile's rays
             const uint32_t etask = v.task_begin + tq;
             const TaskGeom etg = task_geom(v, etask, lane);
-            if (etg.inside) step_epilogue_lane(v, step, GRADS, num_bounces, etg, StateRef{v.state, v.state_stride, etask * EGR_WAVE + (uint32_t)lane});
+            if (etg.inside) step_epilogue_lane(v, step, GRADS, num_bounces, etg, state_of(v, etask, lane));
         }
     }
     __syncthreads();
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_finish(DeviceView v) {
     for (uint32_t task = v.task_begin + blockIdx.x; task < v.task_begin + v.task_count; task += gridDim.x) {
         const TaskGeom tg = task_geom(v, task, lane);
         if (!tg.inside) continue;
-        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
+        const StateRef S = state_of(v, task, lane);
         const uint32_t steps = f2u(S.ld(F_STEPS));
         f3 final = mk3(0, 0, 0);
         for (int s = 0; s < EGR_NSTEPS; s++) {
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(EGR_WAVE) k_export_step_hits(DeviceView v, int
     for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
         const TaskGeom tg = task_geom(v, task, lane);
         if (!tg.inside) continue;
-        StateRef S{v.state, v.state_stride, task * EGR_WAVE + (uint32_t)lane};
+        const StateRef S = state_of(v, task, lane);
         const uint32_t steps = f2u(S.ld(F_STEPS));
         for (int s = 0; s < EGR_NSTEPS; s++) out[(size_t)s * v.num_pixels + tg.pixel_id] = (uint32_t)s < steps ? (int32_t)f2u(S.ld(SF(s, S_NHITS))) : 0;
     }
@@ -515,7 +515,7 @@ uint32_t egr_num_tasks_for_rank(const egr_context *c) {
     uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
     uint32_t M = mtx * mty;
     if ((uint32_t)c->rank >= M) return 0;
-    return 4u * ((M - (uint32_t)c->rank + (uint32_t)c->world - 1) / (uint32_t)c->world);
+    return 4u * ((M - (uint32_t)c->rank + (uint32_t)c->world - 1) / (uint32_t)c->world); // in 8x8 tiles; x 2 / x 4 with smaller tasks (egr_make_view)
 }
 
 // Order of this rank's macro tiles: sort by (XCD chunk block, Z-curve inside the block). The 8 chunks that
@@ -597,7 +597,8 @@ void egr_trace_alloc(egr_context *c) {
     uint64_t blocks = (uint64_t)(bwd_bytes / ((EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4)));
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
     egr_dev_alloc_raw(c, (void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4));
-    egr_dev_alloc_raw(c, (void **)&c->task_last_block, (size_t)EGR_NSTEPS * c->num_tasks_total * sizeof(uint32_t));
+    egr_dev_alloc_raw(c, (void **)&c->task_last_block, (size_t)EGR_NSTEPS * 4u * c->num_tasks_total * sizeof(uint32_t)); // (up to 16 tasks per macro tile)
+    if (const char *e = getenv("EGR_RAYS_PER_TASK")) c->rays_per_task = atoi(e);
     c->state_stride = c->num_tasks_total * EGR_WAVE;
     egr_dev_alloc_raw(c, (void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float));
     EGR_HIP(hipMemset(c->state, 0, (size_t)F_TOTAL * c->state_stride * sizeof(float)));
@@ -624,7 +625,16 @@ DeviceView egr_make_view(const egr_context *c) {
     v.n = c->g.count;
     v.num_nodes = c->num_wide;
     v.rank = c->rank, v.world = c->world;
-    v.num_tasks = egr_num_tasks_for_rank(c);
+    // Task size. 8x8 pixels unless the rank is under-filled: with fewer than two 8x8 tiles per resident wave (a rank of an 8-way
+    // partition at 1080p) every tile starts at once and the launch lasts as long as its heaviest tile - 8x4-pixel tasks halve the
+    // tiles (rank 0 of an emulated 8-way partition: 5.04 -> 4.16 ms dense-init, 3.95 -> 3.71 ms trained-like; 4x4 tasks: 4.12 / 4.12 ms,
+    // the per-ray phases then run at a quarter of the lanes). A ray's candidate LIST ORDER depends on the task shape
+    // (pair walk), so exactly tied depths may composite in another order than with 8x8 tasks (documented deviation (a)).
+    const uint32_t tiles = egr_num_tasks_for_rank(c);
+    uint32_t rpt = c->rays_per_task == 16 || c->rays_per_task == 32 || c->rays_per_task == 64 ? (uint32_t)c->rays_per_task
+                   : (c->world > 1 && tiles < 2u * c->num_slots ? 32u : 64u);
+    v.rays_per_task = rpt, v.task_shift = rpt == 64u ? 2u : rpt == 32u ? 3u : 4u;
+    v.num_tasks = tiles << (v.task_shift - 2u);
     v.task_begin = 0, v.task_count = v.num_tasks, v.queues = c->queues, v.num_strands = (uint32_t)c->strands;
     v.task_macro = c->task_macro;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
@@ -654,16 +664,16 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
         // (no explicit egr_set_strands: all strands when the rank has at least four tiles per wave slot; with fewer - a rank of a
         // multi-GPU partition - concurrent chains only delay each other's heaviest tiles: 4.66 / 4.85 / 4.97 ms with 1 / 2 / 3
         // strands for rank 0 of an 8-way partition, 18.7 / 18.3 / 18.0 ms for the whole image)
-        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : ((uint64_t)v.num_tasks >= 4ull * c->num_slots ? c->strands : 1);
+        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : ((uint64_t)(v.num_tasks >> (v.task_shift - 2u)) >= 4ull * c->num_slots ? c->strands : 1); // (counted in 8x8 tiles)
         const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
         if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
         for (int st = 0; st < S; st++) {
             hipStream_t ls = S > 1 ? c->strand_stream[st] : s;
             if (S > 1) EGR_HIP(hipStreamWaitEvent(ls, c->ev_fork, 0));
             DeviceView w = v;
-            const uint32_t groups = v.num_tasks / 4u; // tasks come in groups of 4 (one macro tile)
-            w.task_begin = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)st) / (uint64_t)S);
-            w.task_count = 4u * (uint32_t)(((uint64_t)groups * (uint64_t)(st + 1)) / (uint64_t)S) - w.task_begin;
+            const uint32_t groups = v.num_tasks >> v.task_shift; // tasks come in groups (one macro tile)
+            w.task_begin = (uint32_t)(((uint64_t)groups * (uint64_t)st) / (uint64_t)S) << v.task_shift;
+            w.task_count = ((uint32_t)(((uint64_t)groups * (uint64_t)(st + 1)) / (uint64_t)S) << v.task_shift) - w.task_begin;
             w.queues = c->queues + EGR_QUEUE_WORDS * st;
             const size_t slot0 = (size_t)st * c->num_slots;
             w.cand_keys += slot0 * c->cand_cap * EGR_WAVE, w.cand_vals += slot0 * c->cand_cap * EGR_WAVE;

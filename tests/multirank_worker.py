@@ -15,6 +15,8 @@ sys.path.insert(0, ROOT)
 syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic")
 ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
 
+os.environ.setdefault("EGR_RAYS_PER_TASK", "64")  # same task shape for the partitioned and the unpartitioned tracer (this image is tiny: a partitioned rank
+                                                   # would otherwise switch to 8x4-pixel tasks, whose candidate lists - and exactly tied hits - come in another order)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")

@@ -440,8 +440,12 @@ def test_candidate_lists_longer_than_capacity_continue_in_extension_blocks(ren, 
         assert np.abs(hs[k] - hb[k]).max() / (np.abs(hb[k]).max() + 1e-30) < 1e-5, k
 
 
-def test_tile_partition_sums_to_full_image(ren, orc, syn):
-    """Multi-GPU split on one device: rank r of 2 traces its tiles only; images tile together, gradients add up."""
+@pytest.mark.parametrize("rays_per_task", [64, 32, 16])
+def test_tile_partition_sums_to_full_image(ren, orc, syn, monkeypatch, rays_per_task):
+    """Multi-GPU split on one device: rank r of 2 traces its tiles only; images tile together, gradients add up - with 8x8-pixel
+    tasks and with the 8x4 / 4x4 tasks an under-filled rank switches to (env EGR_RAYS_PER_TASK pins the shape for every tracer of
+    this test: the order of a ray's candidate list, hence of exactly tied hits, depends on it)."""
+    monkeypatch.setenv("EGR_RAYS_PER_TASK", str(rays_per_task))
     W, H = 80, 48
     g = syn.make_scene(3000, "trained", seed=5)
     cam = syn.default_camera()
@@ -450,8 +454,12 @@ def test_tile_partition_sums_to_full_image(ren, orc, syn):
     with torch.no_grad():
         full(cam_obj(ren, cam))
     img_full = hip_outputs(full)["output_final"]
+    assert psnr(img_full, o.raytrace(False)["output_final"]) > 55  # (this task shape against the oracle, whole image)
     run_grad(ren, full, cam_obj(ren, cam, tg))
     gfull = hip_grads(full)
+    refg = o.raytrace(True, targets=tg)
+    for k in GRAD_KEYS:
+        assert np.abs(gfull[k] - refg[k]).max() / (np.abs(refg[k]).max() + 1e-30) < 1e-3, (rays_per_task, k)
     parts, gparts, counters = [], [], []
     for r in range(2):
         rt, orr = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0))
