@@ -149,7 +149,9 @@ def test_forward_strict_parity_primary(ren, orc, syn, variant):
     assert n_acc <= 1, bad_acc  # measured: 0 on both variants
     # default launches count the records the walk EVALUATED (ellipsoid boxes; include/egr_raytracer.h: egr_set_exact_stats), not the
     # reference's intersection invocations; that count is compared in test_exact_stats_mode_counts_reference_invocations
-    assert 0.5 * ref["num_traversed"].sum() < ht.sum() < 2.0 * ref["num_traversed"].sum()
+    ratio = float(ht.sum()) / float(ref["num_traversed"].sum())
+    report("default_statistic_" + variant, evaluated_over_reference_invocations=round(ratio, 3))
+    assert 0.75 < ratio < 1.35, ratio  # (bench scenes: 0.90 ... 1.07; a regression guard, not a parity claim)
     seeds = rt.cuda_module.get_metadata().random_seeds.cpu().numpy().astype(np.uint32).reshape(H, W)
     assert np.array_equal(seeds, ref["random_seeds"].reshape(H, W))
     c = rt.cuda_module.get_counters()
@@ -250,7 +252,7 @@ def test_golden_fixture(ren, orc, syn):
         assert psnr(out[k], z["ref_" + k]) > 50.0, k
     st = rt.cuda_module.get_stats()
     ht = st.num_traversed_per_pixel.cpu().numpy()
-    assert 0.5 * z["ref_num_traversed"].sum() < ht.sum() < 2.0 * z["ref_num_traversed"].sum()  # evaluated records (default mode)
+    assert 0.75 * z["ref_num_traversed"].sum() < ht.sum() < 1.35 * z["ref_num_traversed"].sum()  # evaluated records (default mode)
     assert (st.num_accumulated_per_pixel.cpu().numpy() != z["ref_num_accumulated"]).mean() < 5e-3
     run_grad(ren, rt, cam_obj(ren, cam, tg))
     gr = hip_grads(rt)
