@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic"); ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
 W, H, N = 1920, 1080, 1_000_000
 world = int(os.environ.get("EMU_WORLD", "1"))
-g = syn.make_scene(N, "trained", seed=0); cam = syn.default_camera(); pc = ren.GaussianParams(g)
+g = syn.make_scene(N, os.environ.get("VARIANT", "trained"), seed=0); cam = syn.default_camera(); pc = ren.GaussianParams(g)
 rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000); m = rt.cuda_module
 m.set_strands(1)
 m.get_config().num_bounces.fill_(int(os.environ["TT_STEP"]))  # the measured step must be the last one (later steps overwrite the stats)
@@ -17,8 +17,13 @@ torch.cuda.synchronize()
 st = m.get_stats()
 t0 = st.num_traversed_per_pixel.view(H, W)[::8, ::8].cpu().numpy().astype(np.int64).ravel()
 t1 = st.num_accumulated_per_pixel.view(H, W)[::8, ::8].cpu().numpy().astype(np.int64).ravel()
+tm = st.num_traversed_per_pixel.view(H, W)[::8, 1::8].cpu().numpy().astype(np.int64).ravel()
 own = t1 > t0
-t0, t1 = t0[own], t1[own]
+t0, t1, tm = t0[own], t1[own], tm[own]
+walk, sel = (tm - t0) * 0.01, (t1 - tm) * 0.01
+order = np.argsort(-(t1 - t0))[:12]
+print("heaviest tasks (us): total / walk / selection+compositing:", [(round(float((t1 - t0)[i]) * 0.01, 1), round(float(walk[i]), 1), round(float(sel[i]), 1)) for i in order])
+print("all tasks: walk share of the task time: mean", float(walk.sum() / (walk.sum() + sel.sum())))
 base = t0.min()
 s, e = (t0 - base) * 0.01, (t1 - base) * 0.01  # us
 dur = e - s
