@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
     p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 3 from four tiles per wave slot, else 1); the per-kernel profile pass always uses 1")
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
+    p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
     p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
     a = p.parse_args()
     if a.config == "B":
@@ -116,6 +117,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         return float(tmax[0]), float(tsum[0])
+
+    if a.prewarm_seconds > 0:
+        xw = torch.randn(4096, 4096, device="cuda")
+        t_end = time.perf_counter() + a.prewarm_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                xw = torch.nn.functional.normalize(xw @ xw, dim=1)
+            torch.cuda.synchronize()
+        del xw
 
     def run_variant(variant, with_profile, with_cpu):
         """Times `steps` passes of the hot path on the `variant` cloud; returns the pieces of the JSON line."""
