@@ -286,6 +286,9 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues, v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9 // diagnostic build: stamps of the WHOLE chain of a task (start, end of every step) in its first pixels
+        unsigned long long chain_t[EGR_NSTEPS + 1] = {__builtin_amdgcn_s_memrealtime(), 0ull, 0ull, 0ull};
+#endif
         for (int step = 0; step <= num_bounces; step++) {
             do { // (a `continue` in the step body ends the step)
                 const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
@@ -298,7 +301,16 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
             const uint32_t etask = v.task_begin + tq;
             const TaskGeom etg = task_geom(v, etask, lane);
             if (etg.inside) step_epilogue_lane(v, step, GRADS, num_bounces, etg, state_of(v, etask, lane));
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9
+            chain_t[step + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9
+        {
+            const TaskGeom ctg = task_geom(v, v.task_begin + tq, lane);
+            if (lane <= EGR_NSTEPS && ctg.inside) v.stats.num_traversed_per_pixel[ctg.pixel_id] = (int32_t)(chain_t[lane] & 0x7FFFFFFFull);
+        }
+#endif
     }
     __syncthreads();
     if (lane < EGR_NSTEPS) {
