@@ -478,6 +478,9 @@ static void refit_boxes(egr_context *c, hipStream_t s) {
 
 void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     const uint32_t n = c->g.count;
+    // the pair walk packs (ray, record) and (ray, wide node) into 32 bits: 6 + 26 (trace.hip). 67M gaussians is beyond any scene this
+    // path has seen (50 GB of records); fail loudly rather than wrap.
+    if (n >= (1u << 26)) throw EgrCheck{hipErrorInvalidValue, "rebuild_bvh: more than 2^26 - 1 gaussians are not supported (record index is packed into 26 bits)"};
     egr_bvh_reserve(c, n);
     c->n_built = n;
     c->num_wide = 0;

@@ -134,7 +134,7 @@ int egr_set_gaussians(egr_context *ctx, const egr_gaussians *gaussians);
 
 /* Raytracer::rebuild_bvh (raytracer.cpp:102-110; optix/bvh_wrapper.h:24-30,118-157): instance transforms from
  * the current parameters + full LBVH build. Synchronises the stream (the reference's build also does). */
-int egr_rebuild_bvh(egr_context *ctx, void *hip_stream);
+int egr_rebuild_bvh(egr_context *ctx, void *hip_stream); /* fails for count >= 2^26 (67M): record indices are packed into 26 bits */
 
 /* Raytracer::update_bvh (raytracer.cpp:100; optix/bvh_wrapper.h:32-59): re-snapshot instance transforms and
  * refit the existing tree. Asynchronous; reads alpha_threshold/exp_power/global_scale_factor on the device
