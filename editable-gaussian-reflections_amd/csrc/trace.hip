@@ -158,6 +158,12 @@ EGR_DI uint4 load_u4_uniform(const uint4 *base, uint32_t idx) { // idx must be w
 // with invq = 1/(d*scale), ncq = -origin_cell*invq. Cells 0 / 65535 are the out-of-frame sentinels (-inf / +inf).
 // The fused form moves a plane by < 0.01 cell (boxes carry a full extra cell each side); for an exactly axis-parallel
 // ray both products are inf and the axis drops out (conservative).
+// The interval part of the slab test: [max of the per-axis entries, min of the per-axis exits] clipped to [tmin, tmax].
+EGR_DI bool slab_clip(float ax, float bx, float ay, float by, float az, float bz, float tmin, float tmax) {
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return t0 <= t1;
+}
 EGR_DI bool qslab_hit(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
     const uint32_t lx = q.x & 0xFFFFu, ly = q.x >> 16, lz = q.y & 0xFFFFu, hx = q.y >> 16, hy = q.z & 0xFFFFu, hz = q.z >> 16;
     const float flx = lx == 0u ? -3.0e38f : (float)lx, fly = ly == 0u ? -3.0e38f : (float)ly, flz = lz == 0u ? -3.0e38f : (float)lz;
@@ -165,9 +171,7 @@ EGR_DI bool qslab_hit(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
     const float ax = fmaf(flx, invq.x, ncq.x), bx = fmaf(fhx, invq.x, ncq.x);
     const float ay = fmaf(fly, invq.y, ncq.y), by = fmaf(fhy, invq.y, ncq.y);
     const float az = fmaf(flz, invq.z, ncq.z), bz = fmaf(fhz, invq.z, ncq.z);
-    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    return t0 <= t1;
+    return slab_clip(ax, bx, ay, by, az, bz, tmin, tmax);
 }
 // Same test when no box of the tree left the build frame (the common case; DeviceView::out_of_frame == 0): no sentinels.
 EGR_DI bool qslab_hit_inframe(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) {
@@ -176,9 +180,7 @@ EGR_DI bool qslab_hit_inframe(uint4 q, f3 invq, f3 ncq, float tmin, float tmax) 
     const float ax = fmaf(flx, invq.x, ncq.x), bx = fmaf(fhx, invq.x, ncq.x);
     const float ay = fmaf(fly, invq.y, ncq.y), by = fmaf(fhy, invq.y, ncq.y);
     const float az = fmaf(flz, invq.z, ncq.z), bz = fmaf(fhz, invq.z, ncq.z);
-    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    return t0 <= t1;
+    return slab_clip(ax, bx, ay, by, az, bz, tmin, tmax);
 }
 EGR_DI float4 fetch_a2(const float4 *p) { return *p; }
 EGR_DI float4 fetch_a2(float4 v) { return v; }
@@ -273,6 +275,9 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
 // says nothing about its cost at the next (measured correlation -0.2 .. -0.07; round 1: 315 -> 364 Mrays/s).
 // CUBE = the exact-statistics build (egr_set_exact_stats): the tree bounds the reference's instance CUBES and every cube overlap
 // is counted, so num_traversed_per_pixel is the reference's number (see forward_task.inc); images are the same.
+#ifndef EGR_LEAN_PUSH
+#define EGR_LEAN_PUSH 1 // pair walk: hit / leaf masks combined on the scalar side, pushes without the spill test while the stack is short
+#endif
 #ifndef EGR_FWD_WAVES
 #define EGR_FWD_WAVES 4 // waves per SIMD the forward chain is built for (register budget 512 / EGR_FWD_WAVES)
 #endif
