@@ -331,7 +331,7 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
 // so per-hit contributions are first summed in a per-wave LDS hash table (ds_add_f32, open addressing on the
 // record index) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
 #ifndef EGR_GT_SLOTS
-#define EGR_GT_SLOTS 64 // slots of the primary step's LDS table (power of two, >= 64). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
+#define EGR_GT_SLOTS 64 // slots of the primary step's LDS table (any count >= 64; multiply-shift hash). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
                         // per CU) and a hit that finds no slot leaves as wide adds anyway (trained 3.46 -> 3.25 ms, dense-init 7.7 -> 4.9 ms)
 #endif
 #ifndef EGR_PRIMARY_TABLE
@@ -374,17 +374,24 @@ EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const floa
 EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane) {
     __syncthreads();
     for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: wide_add_wave is a wave-level operation
-        const int s = s0 + lane;
-        const uint32_t pos = gt_keys[s];
+        const int s = min(s0 + lane, EGR_GT_SLOTS - 1); // (a slot count that is no multiple of 64: the lanes beyond the table idle on its last slot)
+        const bool in_table = s0 + lane < EGR_GT_SLOTS;
+        const uint32_t pos = in_table ? gt_keys[s] : EGR_GT_EMPTY;
         const bool valid = pos != EGR_GT_EMPTY;
-        gt_keys[s] = EGR_GT_EMPTY;
+        if (in_table) gt_keys[s] = EGR_GT_EMPTY;
         float lo[15], hi[15];
 #pragma unroll
-        for (int c = 0; c < 15; c++) lo[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f, gt_vals[c * EGR_GT_SLOTS + s] = 0.0f;
+        for (int c = 0; c < 15; c++) {
+            lo[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f;
+            if (valid) gt_vals[c * EGR_GT_SLOTS + s] = 0.0f; // (an unused slot holds zeros already)
+        }
 #pragma unroll
         for (int c = 0; c < 15; c++) {
             hi[c] = 0.0f;
-            if (15 + c < EGR_GT_COMPS) hi[c] = valid ? gt_vals[(15 + c) * EGR_GT_SLOTS + s] : 0.0f, gt_vals[(15 + c) * EGR_GT_SLOTS + s] = 0.0f;
+            if (15 + c < EGR_GT_COMPS) {
+                hi[c] = valid ? gt_vals[(15 + c) * EGR_GT_SLOTS + s] : 0.0f;
+                if (valid) gt_vals[(15 + c) * EGR_GT_SLOTS + s] = 0.0f;
+            }
         }
         if (__ballot(valid) == 0ull) continue;
         wide_add_wave(v, valid, pos, lo, 0u, stage);
@@ -396,6 +403,9 @@ EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_v
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
 // last bounce first (15 gradient components per hit, straight out as wide adds), then the primary step (22 components through
 // the LDS table). Per-step code: backward_task.inc.
+#ifndef EGR_COMBINE_MASK
+#define EGR_COMBINE_MASK 1 // primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
+#endif
 #ifndef EGR_BWD_WAVES
 #define EGR_BWD_WAVES 3
 #endif

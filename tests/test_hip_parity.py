@@ -607,8 +607,12 @@ def test_composited_hits_are_capped_at_99_batches_of_16(ren, orc, syn):
     run_grad(ren, rt, cam_obj(ren, cam, tg))
     refg = o.raytrace(True, targets=tg)
     gr = hip_grads(rt)
+    # (the stacked gaussians are axis-aligned copies: their rotation gradient cancels to exactly 0 in the oracle's summation order; the
+    # kernel's order - neighbour pre-sums, LDS table, atomics - leaves rounding residue, so a tensor that is zero in the reference is
+    # held to 1e-6 of the largest gradient of the launch instead of to itself)
+    floor = 1e-6 * max(float(np.abs(refg[k]).max()) for k in GRAD_KEYS)
     for k in GRAD_KEYS:
-        assert np.abs(gr[k] - refg[k]).max() / (np.abs(refg[k]).max() + 1e-30) < 1e-3, k
+        assert np.abs(gr[k] - refg[k]).max() / max(float(np.abs(refg[k]).max()), floor, 1e-30) < 1e-3, k
     assert rt.cuda_module.get_counters()[11] == 0
 
 
