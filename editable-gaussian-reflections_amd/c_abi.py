@@ -60,6 +60,7 @@ def lib(path=None):
         for name in ("egr_rebuild_bvh", "egr_update_bvh", "egr_denoise", "egr_reset_lifetime_counters", "egr_debug_check_bvh"):
             getattr(L, name).argtypes = [P, P]
         L.egr_raytrace.argtypes = [P, C.c_int, P]
+        L.egr_update_bvh_ex.argtypes = [P, C.c_uint, P]
         L.egr_set_partition.argtypes = [P, C.c_int, C.c_int]
         L.egr_set_exact_stats.argtypes = [P, C.c_int]
         L.egr_set_strands.argtypes = [P, C.c_int]
@@ -101,8 +102,11 @@ class RawRaytracer:
     def rebuild_bvh(self):  # :102-110
         self._check(self.L.egr_rebuild_bvh(self.ctx, self.stream))
 
-    def update_bvh(self):  # :100
-        self._check(self.L.egr_update_bvh(self.ctx, self.stream))
+    def update_bvh(self, fuse_live=False):  # :100 (fuse_live: egr_update_bvh_ex with EGR_UPDATE_FUSE_LIVE)
+        if fuse_live:
+            self._check(self.L.egr_update_bvh_ex(self.ctx, 1, self.stream))
+        else:
+            self._check(self.L.egr_update_bvh(self.ctx, self.stream))
 
     def raytrace(self, grads_enabled):  # :81-94
         self._check(self.L.egr_raytrace(self.ctx, 1 if grads_enabled else 0, self.stream))

@@ -103,6 +103,7 @@ int egr_set_gaussians(egr_context *c, const egr_gaussians *g) {
     if (!c || !g) return 1;
     c->g = *g;
     c->have_gaussians = true;
+    c->live_fresh = false;
     return guarded(c, [&] { egr_bvh_reserve(c, g->count); });
 }
 
@@ -141,15 +142,20 @@ int egr_rebuild_bvh(egr_context *c, void *stream) {
     return guarded(c, [&] { egr_bvh_rebuild(c, (hipStream_t)stream); });
 }
 
-int egr_update_bvh(egr_context *c, void *stream) {
+int egr_update_bvh_ex(egr_context *c, unsigned flags, void *stream) {
     if (!c || require_ready(c, true)) return 1;
+    if (flags & ~(unsigned)EGR_UPDATE_FUSE_LIVE) {
+        c->last_error = "libegr_hip: egr_update_bvh_ex: unknown flag";
+        return 1;
+    }
     return guarded(c, [&] {
         hipStream_t s = (hipStream_t)stream;
         if (c->timing) EGR_HIP(hipEventRecord(c->ev_ub0, s));
-        egr_bvh_refit(c, s);
+        egr_bvh_refit(c, s, (flags & EGR_UPDATE_FUSE_LIVE) != 0);
         if (c->timing) EGR_HIP(hipEventRecord(c->ev_ub1, s)), c->have_ub = true;
     });
 }
+int egr_update_bvh(egr_context *c, void *stream) { return egr_update_bvh_ex(c, 0u, stream); }
 
 int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
     if (!c || require_ready(c, true)) return 1;

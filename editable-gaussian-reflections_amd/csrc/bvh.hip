@@ -39,8 +39,12 @@ inline int nblk(uint64_t n, int bs = BS) { return (int)((n + bs - 1) / bs); }
 // Records are stored at the gaussian's MORTON-SORTED position (pos_of_gid), i.e. in leaf order: rays that are close
 // in space then read neighbouring 48-B records (same / adjacent cache lines) instead of lines scattered over the
 // whole array - the scene's own order is arbitrary (the reference never sorts its clouds).
+// `live` (egr_update_bvh_ex with EGR_UPDATE_FUSE_LIVE): also write what k_live (trace.hip) writes at every launch - the activated appearance
+// and the (f0.z, roughness, opacity, sigma) quarter of the test record - so that the raytrace that follows immediately skips that pass
+// over the cloud (the records' lines are being written here anyway).
 __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, egr_config cfg, const uint32_t *__restrict__ pos_of_gid,
-                                                  float4 *__restrict__ inst_w, float4 *__restrict__ inst_m, float *__restrict__ aabb, int cube) {
+                                                  float4 *__restrict__ inst_w, float4 *__restrict__ inst_m, float *__restrict__ aabb, int cube,
+                                                  float4 *__restrict__ app, int live) {
     uint32_t i = blockIdx.x * BS + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = pos_of_gid ? pos_of_gid[i] : i;
@@ -87,6 +91,11 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
         inst_w[4 * slot + a] = usable ? Wr[a] : make_float4(0.f, 0.f, 0.f, 2.f); // 64-B record: rows 0-2 = W, row 3 = live quarter (k_live)
         aabb[6 * i + a] = usable ? lo[a] : 3.0e38f;
         aabb[6 * i + 3 + a] = usable ? hi[a] : -3.0e38f;
+    }
+    if (live) { // the same expressions as k_live (utils/helpers.cu:10-33)
+        app[2 * (size_t)slot] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
+        app[2 * (size_t)slot + 1] = make_float4(g.normal[3 * i + 1], g.normal[3 * i + 2], clip01_act(g.f0[3 * i]), clip01_act(g.f0[3 * i + 1]));
+        inst_w[4 * (size_t)slot + 3] = make_float4(clip01_act(g.f0[3 * i + 2]), clip01_act(g.roughness[i]), opacity, sf);
     }
 }
 
@@ -482,6 +491,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     // path has seen (50 GB of records); fail loudly rather than wrap.
     if (n >= (1u << 26)) throw EgrCheck{hipErrorInvalidValue, "rebuild_bvh: more than 2^26 - 1 gaussians are not supported (record index is packed into 26 bits)"};
     egr_bvh_reserve(c, n);
+    c->live_fresh = false; // the records move
     c->n_built = n;
     c->num_wide = 0;
     c->max_depth = 0;
@@ -492,7 +502,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->bvh_valid = true;
         return;
     }
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0); // boxes for the frame
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0, c->app, 0); // boxes for the frame
     uint32_t *bounds = c->scratch_u32, *counters = c->scratch_u32 + 16;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, bounds);
     hipLaunchKernelGGL(k_bounds, dim3(nblk(n)), dim3(BS), 0, s, n, c->aabb, bounds);
@@ -515,7 +525,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     size_t bytes = c->sort_tmp_bytes;
     EGR_HIP(rocprim::radix_sort_pairs(c->sort_tmp, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)n, 0, 63, s));
     hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(n)), dim3(BS), 0, s, n, c->vals_out, c->pos_of_gid);
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0); // records in leaf order
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0, c->app, 0); // records in leaf order
     if (n == 1) { // a single leaf under a one-child root
         uint4 root[EGR_WIDTH];
         for (int k = 0; k < EGR_WIDTH; k++) root[k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, k == 0 ? (EGR_LEAF_FLAG | 0u) : EGR_EMPTY_SLOT);
@@ -560,12 +570,14 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     c->bvh_valid = true;
 }
 
-void egr_bvh_refit(egr_context *c, hipStream_t s) {
+void egr_bvh_refit(egr_context *c, hipStream_t s, bool fuse_live) {
     const uint32_t n = c->g.count;
     if (!c->bvh_valid || n != c->n_built) throw EgrCheck{hipErrorInvalidValue, "update_bvh: tree was built for a different gaussian count; call rebuild_bvh"};
     c->boxes_are_cubes = c->exact_stats;
     if (n == 0) return;
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0);
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0,
+                       c->app, fuse_live ? 1 : 0);
+    c->live_fresh = fuse_live;
     refit_boxes(c, s);
 }
 

@@ -130,6 +130,7 @@ struct egr_context {
     int64_t fwd_capacity = 0, bwd_capacity = 0;
     int rank = 0, world = 1;
     bool bound = false, have_gaussians = false, bvh_valid = false;
+    bool live_fresh = false; // the last egr_update_bvh_ex(EGR_UPDATE_FUSE_LIVE) wrote the live records; consumed by the next raytrace, dropped by rebuild / set_gaussians
     egr_gaussians g{};
     egr_config cfg{};
     egr_camera cam{};
@@ -224,7 +225,7 @@ template <class T> void egr_dev_free(egr_context *c, T *&p) {
 void egr_bvh_free(egr_context *c);
 void egr_bvh_reserve(egr_context *c, uint32_t n);
 void egr_bvh_rebuild(egr_context *c, hipStream_t s);
-void egr_bvh_refit(egr_context *c, hipStream_t s);
+void egr_bvh_refit(egr_context *c, hipStream_t s, bool fuse_live = false);
 int egr_bvh_check(egr_context *c, hipStream_t s, std::string &msg);
 // trace.hip
 void egr_trace_alloc(egr_context *c);

@@ -384,7 +384,9 @@ struct Raytracer : torch::CustomClassHolder {
     }
     void denoise() { check(egr_denoise(ctx, current_stream()), "denoise"); }
     void reset_accumulators() { framebuffer_data->reset_accumulators(); }
-    void update_bvh() { check(egr_update_bvh(ctx, current_stream()), "update_bvh"); }
+    // fuse_live (addition; default = the reference's update_bvh()): the pass also writes the live per-gaussian records and the NEXT raytrace()
+    // skips its own pass over the cloud - for callers that run update_bvh() and raytrace() back to back (egr_update_bvh_ex)
+    void update_bvh(bool fuse_live) { check(egr_update_bvh_ex(ctx, fuse_live ? EGR_UPDATE_FUSE_LIVE : 0u, current_stream()), "update_bvh"); }
     void rebuild_bvh() { check(egr_rebuild_bvh(ctx, current_stream()), "rebuild_bvh"); }
     void resize(int64_t n) { // raytracer.cpp:112-120
         gaussian_data->resize(n);
@@ -446,7 +448,7 @@ struct Raytracer : torch::CustomClassHolder {
             .def("raytrace", &Raytracer::raytrace)
             .def("denoise", &Raytracer::denoise)
             .def("reset_accumulators", &Raytracer::reset_accumulators)
-            .def("update_bvh", &Raytracer::update_bvh)
+            .def("update_bvh", &Raytracer::update_bvh, "", {torch::arg("fuse_live") = false})
             .def("rebuild_bvh", &Raytracer::rebuild_bvh)
             .def("resize", &Raytracer::resize)
             .def("get_camera", [](const Self &self) { return self->camera_data; })

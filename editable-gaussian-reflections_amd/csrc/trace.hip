@@ -681,7 +681,9 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
     hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
     EGR_HIP(hipMemsetAsync(c->stats.num_accumulated_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s)); // stats.h:25-28
     EGR_HIP(hipMemsetAsync(c->stats.num_traversed_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s));
-    if (v.n) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v, grads ? 1 : 0);
+    // (skipped when the egr_update_bvh_ex(EGR_UPDATE_FUSE_LIVE) just before this launch wrote the same records from the same parameters)
+    if (v.n && !c->live_fresh) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v, grads ? 1 : 0);
+    c->live_fresh = false;
     egr_stamp_end(c, s);
     if (v.num_tasks) {
         // Strands: slices of the task order (whole macro tiles), each with its own queues and scratch slots, each running its

@@ -177,7 +177,8 @@ class GaussianRaytracer:
                     buf.zero_()
         grads = torch.is_grad_enabled()
         if grads or force_update_bvh:
-            self.cuda_module.update_bvh()
+            # raytrace() follows with the same parameter values: one pass over the cloud writes the snapshot AND the live records
+            self.cuda_module.update_bvh(True)
         if not grads:
             self._set_full_image(True)
         try:

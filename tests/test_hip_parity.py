@@ -329,6 +329,59 @@ def test_update_bvh_snapshot_semantics(ren, orc, syn, bounces):
     assert psnr(ref["output_rgb"][0], ref2["output_rgb"][0]) < 40  # the two states really differ
 
 
+def test_update_bvh_fuse_live_is_the_same_launch_and_later_launches_read_live_values(ren, orc, syn):
+    """update_bvh(fuse_live=True) (egr_update_bvh_ex, what GaussianRaytracer.__call__ uses) writes the live records in the transform pass and the
+    NEXT raytrace skips its own pass: outputs and gradients must be bit-identical to update_bvh() + raytrace(); the launch after that reads
+    the live tensors again (recolouring without update_bvh shows), and a rebuild between the fused update and the launch drops the flag
+    (the records move)."""
+    W, H = 64, 48
+    g = syn.make_scene(3000, "trained", seed=4)
+    cam = syn.default_camera()
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=2))
+    m = rt.cuda_module
+    tg = syn.make_targets(W, H)
+    with torch.no_grad():
+        rt(cam_obj(ren, cam, tg))  # camera, targets, parameter export
+
+    def launch(fused, grads, rebuild=False):
+        m.get_metadata().total_num_calls.zero_()
+        rt.zero_grad()
+        m.get_gaussians().total_weight.zero_()
+        m.update_bvh(True) if fused else m.update_bvh()
+        if rebuild:
+            m.rebuild_bvh()
+        with torch.set_grad_enabled(grads):
+            m.raytrace()
+        torch.cuda.synchronize()
+        return hip_grads(rt) if grads else hip_outputs(rt)
+
+    a, b = launch(False, False), launch(True, False)
+    for k in OUT_KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    # gradients: same records, same arithmetic; the atomics' order is the only freedom
+    ga, gb = launch(False, True), launch(True, True)
+    for k in GRAD_KEYS:
+        assert np.abs(ga[k] - gb[k]).max() <= 1e-5 * max(float(np.abs(ga[k]).max()), 1e-30), k
+    # the launch AFTER the fused pair reads the live tensors again
+    launch(True, False)
+    m.get_gaussians().rgb.copy_(1.0 - m.get_gaussians().rgb)
+    m.get_metadata().total_num_calls.zero_()
+    with torch.no_grad():
+        m.raytrace()
+    recoloured = hip_outputs(rt)
+    assert psnr(recoloured["output_rgb"][0], a["output_rgb"][0]) < 40
+    g2 = {k: v.copy() for k, v in g.items()}
+    g2["rgb"] = (1.0 - g["rgb"]).astype(np.float32)
+    o.set_gaussians(g2)
+    o.total_num_calls = 0
+    ref = o.raytrace(False)
+    assert psnr(recoloured["output_rgb"][0], ref["output_rgb"][0]) > 60
+    # fused update, then a rebuild (records move), then the launch: same picture as the plain sequence
+    c = launch(True, False, rebuild=True)
+    for k in ("output_rgb", "output_final", "output_depth"):
+        assert psnr(c[k], recoloured[k]) > 100, k
+
+
 def test_accumulate_samples(ren, orc, syn):
     W, H = 40, 24
     g = syn.make_scene(1500, "trained", seed=4)
