@@ -253,9 +253,17 @@ def main():
                 if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                     traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
                     src = f"profiles/{ROUND}/pmc_summary.json[{a.config}_{variant}] (rocprofv3 --pmc, this round, same workload; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
-                return {"bound": "hbm", "kernel": k, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                        "traffic": traffic, "traffic_over_algorithmic": round(traffic / cands[k], 3) if traffic else None, "traffic_source": src,
-                        "avg_kernel_ms": round(kern[k], 4), "algorithmic_bytes_per_launch": cands[k]}
+                r = {"bound": "hbm", "kernel": k, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                     "traffic": traffic, "traffic_over_algorithmic": round(traffic / cands[k], 3) if traffic else None, "traffic_source": src,
+                     "avg_kernel_ms": round(kern[k], 4), "algorithmic_bytes_per_launch": cands[k]}
+                if k == "backward_chain":
+                    # what actually bounds this kernel: it sends its gradients as 64-B records of 16 non-returning fp32 atomic adds, and the GPU
+                    # retires 21.1 G such records / s whatever their footprint (tools/atomic_rate.hip, profiles/r3/atomic_rate.txt)
+                    rec = float(cc[13])
+                    r.update({"atomic_records_per_launch": int(rec), "atomic_record_rate_G_per_s": round(rec / (kern[k] * 1e-3) / 1e9, 2),
+                              "atomic_record_peak_G_per_s": 21.1, "atomic_record_frac": round(rec / (kern[k] * 1e-3) / 21.1e9, 4),
+                              "atomic_record_peak_source": "tools/atomic_rate.hip on MI355X: 16-lane (64-B) fp32 atomic-add records to pseudo-random gradient rows, 0.1 MB .. 268 MB footprint"})
+                return r
 
             roof = roof_of(dom)
             roof.update({"evaluated_frac": round((fwd_eval if dom == "forward_chain" else cands[dom]) / (kern[dom] * 1e-3) / 1e9 / 8000.0, 5),

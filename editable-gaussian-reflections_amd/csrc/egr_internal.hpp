@@ -105,7 +105,7 @@ enum ControlWord : int {
     CW_ACCEPTED = 0,    // per-step 64-bit counters: accepted candidates = what the reference inserts into its forward list
     CW_HIT_BUMP = 8,    // arena block bump allocator
     CW_STATUS = 9,
-    CW_BUCKET_RECORDS = 7, // gradient records the bounce-step backward added to the gradient rows in this launch
+    CW_BUCKET_RECORDS = 7, // 64-B gradient records (wide adds) the backward chain sent to the gradient rows in this launch
     CW_EXT_BUMP = 6,       // candidate-list extension blocks handed out in this launch
     CW_RAYS = 10,       // per-step 64-bit counters (two words each): rays[3], candidates[3], composited[3]
     CW_CAND = 16,

@@ -371,7 +371,8 @@ EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const floa
 }
 
 // Flush of the primary step's LDS table: every used slot leaves as two 16-lane records (components 0-14 and 15-21 of the row).
-EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane) {
+EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane) {
+    uint32_t sent = 0u; // records (two per used slot)
     __syncthreads();
     for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: wide_add_wave is a wave-level operation
         const int s = min(s0 + lane, EGR_GT_SLOTS - 1); // (a slot count that is no multiple of 64: the lanes beyond the table idle on its last slot)
@@ -396,8 +397,10 @@ EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_v
         if (__ballot(valid) == 0ull) continue;
         wide_add_wave(v, valid, pos, lo, 0u, stage);
         wide_add_wave(v, valid, pos, hi, 15u, stage);
+        sent += 2u * (uint32_t)__popcll(__ballot(valid));
     }
     __syncthreads();
+    return sent;
 }
 
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
@@ -405,6 +408,9 @@ EGR_DI void grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_v
 // the LDS table). Per-step code: backward_task.inc.
 #ifndef EGR_COMBINE_MASK
 #define EGR_COMBINE_MASK 1 // primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
+#endif
+#ifndef EGR_BWD_COMPACT
+#define EGR_BWD_COMPACT 1 // bounce-step backward: per-ray suffix sums first, then the per-hit geometry with one lane per HIT (backward_task.inc)
 #endif
 #ifndef EGR_BWD_WAVES
 #define EGR_BWD_WAVES 3
@@ -414,6 +420,10 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
     __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
     __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (wide_add_wave)
+#if EGR_BWD_COMPACT
+    __shared__ uint2 bitems[4 * EGR_WAVE];  // bounce steps: (ray | row << 6, dL/dalpha) of the hits of a chunk of four rows
+    __shared__ float bdl[3 * EGR_WAVE];     // bounce steps: the rays' radiance gradient
+#endif
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < EGR_GT_COMPS * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
     __syncthreads();
@@ -421,7 +431,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
     const float eps_scale_grad = *v.cfg.eps_scale_grad;
     const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
     uint32_t cur_q = blockIdx.x & 7u;
-    uint32_t records = 0u; // wide-add records this wave sent from bounce steps (egr_counters::bucket_records)
+    uint32_t records = 0u; // 64-B gradient records this wave sent: bounce hits, primary hits without a table slot (two each), flushed table slots (two each) (egr_counters::bucket_records)
 
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q);

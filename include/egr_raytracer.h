@@ -104,7 +104,7 @@ typedef struct egr_counters {
     uint32_t lifetime_launches;
     uint32_t status;                     /* EGR_STATUS_* bit mask of the last launch                          */
     uint32_t bvh_depth;
-    uint32_t bucket_records;             /* 64-B gradient records the bounce-step backward added to the rows (grad launches) */
+    uint32_t bucket_records;             /* 64-B gradient records (16-lane atomic adds) the backward chain sent to the gradient rows in this launch */
     uint64_t device_bytes;               /* device memory this context holds right now (scratch, arena, ray state, tree, records);
                                           * the caller's tensors (parameters, gradients, framebuffer) are not included          */
     uint32_t arena_blocks_used, arena_blocks_cap; /* composited-hit arena (backward capacity): 9-KB blocks the last grad launch took / holds */
