@@ -27,6 +27,9 @@ done
 pass C init 3 TCC_HIT TCC_MISS TCC_REQ
 pass C init 4 TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TOTAL_CACHE_ACCESSES
 pass C init 5 TA_TA_BUSY TCP_GATE_EN1 TCP_PENDING_STALL_CYCLES
+pass C init 6 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
+pass C init 7 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
+pass C init 8 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU
 pass C trained 3 TCC_HIT TCC_MISS TCC_REQ
 pass C trained 4 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
 pass C trained 5 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
