@@ -142,8 +142,8 @@ int egr_rebuild_bvh(egr_context *ctx, void *hip_stream); /* fails for count >= 2
 int egr_update_bvh(egr_context *ctx, void *hip_stream);
 /* The same with flags. EGR_UPDATE_FUSE_LIVE: the pass over the cloud that snapshots the transforms also writes the LIVE per-gaussian
  * records (activated appearance, opacity, sigma: what the reference's read_* helpers fetch inside the launch, utils/helpers.cu:10-33),
- * and the NEXT egr_raytrace does not repeat that pass. The caller promises that the parameter tensors are not written between this
- * call and that egr_raytrace (the reference's caller, gaussian_raytracer.py:139-142, calls the two back to back); every later launch
+ * and the NEXT egr_raytrace does not repeat that pass. The caller promises that the parameter tensors and the config scalars the live
+ * records depend on (alpha_threshold, exp_power) are not written between this call and that egr_raytrace (the reference's caller, gaussian_raytracer.py:139-142, calls the two back to back); every later launch
  * reads the live parameters again as usual. One pass of ~130 B per gaussian less per training iteration. */
 #define EGR_UPDATE_FUSE_LIVE 1u
 int egr_update_bvh_ex(egr_context *ctx, unsigned flags, void *hip_stream);

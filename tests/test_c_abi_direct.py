@@ -94,6 +94,9 @@ def test_c_abi_without_the_torch_shim_matches_the_shim_bit_for_bit():
     c2 = raw.counters()
     assert c1.status == 0 and c2.status == 0 and c1.rays[0] == W * H and int(T["total_num_calls"]) == 2 and bool(T["grads_enabled"])
     assert c2.device_bytes > 0 and c2.arena_blocks_used > 0
+    # egr_update_bvh_ex: unknown flags are refused with a message; EGR_UPDATE_FUSE_LIVE is the sequence the shim path below runs
+    assert raw.L.egr_update_bvh_ex(raw.ctx, 2, raw.stream) != 0 and b"unknown flag" in raw.L.egr_last_error(raw.ctx)
+    raw.update_bvh(fuse_live=True)
     # ---- the same through torch.classes.raytracer (the shim), reference call sequence of GaussianRaytracer.__call__
     rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=8_000_000, ppll_backward_size=8_000_000)
     camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"], **{k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()})
