@@ -279,6 +279,25 @@ def test_backward_parity(ren, orc, syn, bounces):
     assert rt.cuda_module.get_counters()[11] == 0
 
 
+def test_backward_parity_long_bounce_chains(ren, orc, syn):
+    """Bounce rays through a translucent cloud composite 20+ hits: their backward chains span several arena blocks per bounce step, which
+    the two-pass bounce backward (suffix sums per ray, geometry per hit; backward_task.inc) walks in chunks of four rows. Surfaces are made
+    specular enough for the bounces to happen at all (a dense-init cloud's accumulated normal is too short for most rays)."""
+    from hip_common import generic_targets, grads_vs_oracle_listing_flipped_pixels
+
+    W, H = 64, 48
+    g = syn.make_scene(4000, "init", seed=13)
+    g["opacity"] = np.full_like(g["opacity"], np.log(0.35 / 0.65)).astype(np.float32)  # sigmoid^-1(0.35): long lists AND a usable normal
+    cam = syn.default_camera()
+    tg = generic_targets(syn, W, H)
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=2))
+    grads_vs_oracle_listing_flipped_pixels(ren, rt, o, cam_obj(ren, cam, tg), tg, W, H, "long_bounce_chains_grads")
+    hits = rt.cuda_module.debug_step_hits().numpy()  # [3,H,W] of the last grad launch
+    report("long_bounce_chains", max_hits_per_step=[int(hits[s].max()) for s in range(3)], bounce_rays=int((hits[1] > 0).sum()))
+    assert int(hits[1].max()) > 16 and int((hits[1] > 8).sum()) > 50  # chains of three and more blocks exist, many of two
+    assert rt.cuda_module.get_counters()[11] == 0
+
+
 def test_grad_mode_writes_no_images_and_accumulates_grads(ren, orc, syn):
     """Quirk Q7 (shaders.cu:155-169): outputs are only written when grads are disabled; grads add up across calls."""
     W, H = 32, 32
