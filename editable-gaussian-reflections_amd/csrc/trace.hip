@@ -275,9 +275,6 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
 // says nothing about its cost at the next (measured correlation -0.2 .. -0.07; round 1: 315 -> 364 Mrays/s).
 // CUBE = the exact-statistics build (egr_set_exact_stats): the tree bounds the reference's instance CUBES and every cube overlap
 // is counted, so num_traversed_per_pixel is the reference's number (see forward_task.inc); images are the same.
-#ifndef EGR_LEAN_PUSH
-#define EGR_LEAN_PUSH 1 // pair walk: hit / leaf masks combined on the scalar side, pushes without the spill test while the stack is short
-#endif
 #ifndef EGR_FWD_WAVES
 #define EGR_FWD_WAVES 4 // waves per SIMD the forward chain is built for (register budget 512 / EGR_FWD_WAVES)
 #endif
