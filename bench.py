@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
     p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 3 from four tiles per wave slot, else 1); the per-kernel profile pass always uses 1")
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
+    p.add_argument("--emulate-rank", type=int, default=0, help="which rank's tiles --emulate-world traces")
     p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
     p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
     a = p.parse_args()
@@ -139,7 +140,7 @@ def main():
             m.set_strands(a.strands)
         if a.emulate_world > 1:
             assert world == 1
-            m.set_partition(0, a.emulate_world)
+            m.set_partition(a.emulate_rank, a.emulate_world)
 
         def one_step():
             if a.forward_only:
