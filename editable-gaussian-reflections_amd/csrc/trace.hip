@@ -35,7 +35,7 @@
 #include "egr_epilogue.hpp" // (includes egr_state.hpp) the step epilogue, for the fused per-tile chain
 
 #ifndef EGR_GPOP
-#define EGR_GPOP 4 // pair walk: a walk batch pops up to 8 x EGR_GPOP (ray, node) pairs, EGR_GPOP per lane group
+#define EGR_GPOP 5 // pair walk: a walk batch pops up to 8 x EGR_GPOP (ray, node) pairs, EGR_GPOP per lane group (5 since the loop is instantiated per decode: 62 -> 41 spilled VGPRs; before that 4 was best)
 #endif
 #ifndef EGR_PIPELINE
 #define EGR_PIPELINE 1 // pair walk: issue an evaluation batch's record fetches and a walk batch's node fetches together (0: one kind of batch per iteration)
