@@ -64,7 +64,9 @@ def lib(path=None):
         L.egr_set_partition.argtypes = [P, C.c_int, C.c_int]
         L.egr_set_exact_stats.argtypes = [P, C.c_int]
         L.egr_set_strands.argtypes = [P, C.c_int]
+        L.egr_set_rays_per_task.argtypes = [P, C.c_int]
         L.egr_get_counters.argtypes = [P, C.POINTER(egr_counters), P]
+        L.egr_get_counters_ex.argtypes = [P, P, C.c_size_t, P]
         L.egr_last_error.argtypes = [P]
         L.egr_last_error.restype = C.c_char_p
         L.egr_version.restype = C.c_char_p
@@ -114,9 +116,9 @@ class RawRaytracer:
     def denoise(self):  # :96
         self._check(self.L.egr_denoise(self.ctx, self.stream))
 
-    def counters(self):  # synchronises the stream
+    def counters(self):  # synchronises the stream; the sized call: the library never writes more than THIS mirror of the struct holds
         c = egr_counters()
-        self._check(self.L.egr_get_counters(self.ctx, C.byref(c), self.stream))
+        self._check(self.L.egr_get_counters_ex(self.ctx, C.byref(c), C.sizeof(c), self.stream))
         return c
 
     def close(self):

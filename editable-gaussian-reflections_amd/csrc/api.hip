@@ -52,7 +52,7 @@ template <class F> int guarded(egr_context *c, F &&f) {
 
 extern "C" {
 
-const char *egr_version(void) { return "egr-hip 0.1 (gfx950)"; }
+const char *egr_version(void) { return "egr-hip 0.4 (gfx950)"; } // 0.4: egr_counters grew (round 3), egr_get_counters_ex, egr_set_rays_per_task
 
 int egr_create(egr_context **out, int device, int width, int height, int64_t ppll_forward_size, int64_t ppll_backward_size) {
     if (!out || width <= 0 || height <= 0) return 1;
@@ -96,6 +96,7 @@ int egr_bind(egr_context *c, const egr_camera *camera, const egr_config *config,
     if (!c || !camera || !config || !framebuffer || !metadata || !stats) return 1;
     c->cam = *camera, c->cfg = *config, c->fb = *framebuffer, c->meta = *metadata, c->stats = *stats;
     c->bound = true;
+    c->live_fresh = false; // other config scalars: the live records of a fused update are not trusted across a re-bind
     return 0;
 }
 
@@ -115,7 +116,14 @@ int egr_set_partition(egr_context *c, int rank, int world) {
 
 int egr_set_exact_stats(egr_context *c, int enable) {
     if (!c) return 1;
+    c->live_fresh = false;
     c->exact_stats = enable != 0; // the boxes change at the next egr_update_bvh / egr_rebuild_bvh; egr_raytrace checks that they did
+    return 0;
+}
+
+int egr_set_rays_per_task(egr_context *c, int rays_per_task) {
+    if (!c || !(rays_per_task == 0 || rays_per_task == 16 || rays_per_task == 32 || rays_per_task == 64)) return 1;
+    c->rays_per_task = rays_per_task;
     return 0;
 }
 
@@ -143,7 +151,9 @@ int egr_rebuild_bvh(egr_context *c, void *stream) {
 }
 
 int egr_update_bvh_ex(egr_context *c, unsigned flags, void *stream) {
-    if (!c || require_ready(c, true)) return 1;
+    if (!c) return 1;
+    c->live_fresh = false; // set again by a refit that wrote the live records (egr_bvh_refit), and only if it got that far
+    if (require_ready(c, true)) return 1;
     if (flags & ~(unsigned)EGR_UPDATE_FUSE_LIVE) {
         c->last_error = "libegr_hip: egr_update_bvh_ex: unknown flag";
         return 1;
@@ -158,7 +168,14 @@ int egr_update_bvh_ex(egr_context *c, unsigned flags, void *stream) {
 int egr_update_bvh(egr_context *c, void *stream) { return egr_update_bvh_ex(c, 0u, stream); }
 
 int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
-    if (!c || require_ready(c, true)) return 1;
+    if (!c) return 1;
+    // The live records of an egr_update_bvh_ex(EGR_UPDATE_FUSE_LIVE) are honoured by the raytrace that is the NEXT call on this context
+    // and by nothing else: the flag is consumed here, before anything can fail, so a launch that is refused (stale tree, exact-stats
+    // gate) or any other call in between (egr_bind, egr_set_gaussians, egr_set_exact_stats, rebuild, another update) leaves the next
+    // launch reading the live tensors itself.
+    const bool live_fresh = c->live_fresh;
+    c->live_fresh = false;
+    if (require_ready(c, true)) return 1;
     if (c->exact_stats != c->boxes_are_cubes) {
         c->last_error = "libegr_hip: egr_set_exact_stats changed since the tree was last refitted; call egr_update_bvh or egr_rebuild_bvh first";
         return 1;
@@ -167,7 +184,7 @@ int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
         hipStream_t s = (hipStream_t)stream;
         c->stamps_used = 0;
         if (c->timing) EGR_HIP(hipEventRecord(c->ev_rt0, s));
-        egr_trace_launch(c, grads_enabled != 0, s);
+        egr_trace_launch(c, grads_enabled != 0, live_fresh, s);
         if (c->timing) EGR_HIP(hipEventRecord(c->ev_rt1, s)), c->have_rt = true;
     });
 }
@@ -180,9 +197,12 @@ int egr_denoise(egr_context *c, void *stream) {
     });
 }
 
-int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
-    if (!c || !out) return 1;
-    return guarded(c, [&] {
+int egr_get_counters(egr_context *c, egr_counters *out, void *stream) { return egr_get_counters_ex(c, out, sizeof(egr_counters), stream); }
+
+int egr_get_counters_ex(egr_context *c, void *out_raw, size_t out_bytes, void *stream) {
+    if (!c || !out_raw) return 1;
+    egr_counters full{}, *out = &full; // filled completely, then the caller gets as much of it as its struct holds
+    const int rc = guarded(c, [&] {
         // the control block only crosses PCIe when somebody asks for it (nothing does inside a training iteration)
         EGR_HIP(hipMemcpyAsync(c->control_host, c->control, CW_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
         EGR_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -216,6 +236,8 @@ int egr_get_counters(egr_context *c, egr_counters *out, void *stream) {
                         (unsigned long long)u64(CW_DBG2 + 8 + 4 * k + 2));
         }
     });
+    if (rc == 0) memcpy(out_raw, &full, out_bytes < sizeof(full) ? out_bytes : sizeof(full));
+    return rc;
 }
 
 int egr_reset_lifetime_counters(egr_context *c, void *stream) {
@@ -281,7 +303,7 @@ int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, voi
 }
 
 int egr_debug_get_step_hits(egr_context *c, int32_t *host_out, void *stream) {
-    if (!c || !host_out) return 1;
+    if (!c || !host_out || require_ready(c, false)) return 1;
     return guarded(c, [&] { egr_export_step_hits(c, host_out, (hipStream_t)stream); });
 }
 

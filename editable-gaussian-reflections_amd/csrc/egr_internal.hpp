@@ -130,7 +130,7 @@ struct egr_context {
     int64_t fwd_capacity = 0, bwd_capacity = 0;
     int rank = 0, world = 1;
     bool bound = false, have_gaussians = false, bvh_valid = false;
-    bool live_fresh = false; // the last egr_update_bvh_ex(EGR_UPDATE_FUSE_LIVE) wrote the live records; consumed by the next raytrace, dropped by rebuild / set_gaussians
+    bool live_fresh = false; // the last API call was an egr_update_bvh_ex(EGR_UPDATE_FUSE_LIVE) that wrote the live records; consumed (cleared) on entry of egr_raytrace, dropped by every other call that touches the context
     egr_gaussians g{};
     egr_config cfg{};
     egr_camera cam{};
@@ -230,7 +230,7 @@ int egr_bvh_check(egr_context *c, hipStream_t s, std::string &msg);
 // trace.hip
 void egr_trace_alloc(egr_context *c);
 void egr_trace_free(egr_context *c);
-void egr_trace_launch(egr_context *c, bool grads, hipStream_t s);
+void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s);
 uint32_t egr_num_tasks_for_rank(const egr_context *c);
 void egr_build_task_order(egr_context *c);
 DeviceView egr_make_view(const egr_context *c);

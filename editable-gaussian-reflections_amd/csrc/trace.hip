@@ -548,11 +548,21 @@ __global__ void k_copy3(const float *__restrict__ src, float *__restrict__ dst, 
 
 uint32_t egr_num_tasks_for_rank(const egr_context *c) {
     uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
-    uint32_t M = mtx * mty;
-    if ((uint32_t)c->rank >= M) return 0;
-    return 4u * ((M - (uint32_t)c->rank + (uint32_t)c->world - 1) / (uint32_t)c->world); // in 8x8 tiles; x 2 / x 4 with smaller tasks (egr_make_view)
+    const uint32_t M = mtx * mty, world = (uint32_t)c->world, rank = (uint32_t)c->rank;
+    // every block of `world` consecutive Z-order positions holds each rank once; in the last, partial block b the positions j < rem go
+    // to ranks (j + b) % world (see egr_build_task_order)
+    const uint32_t full = M / world, rem = M % world;
+    const uint32_t extra = ((rank + world - full % world) % world) < rem ? 1u : 0u;
+    return 4u * (full + extra); // in 8x8 tiles; x 2 / x 4 with smaller tasks (egr_make_view)
 }
 
+// Which rank owns which macro tile ("tile k -> GPU k mod world after a Morton shuffle"): the macro tiles are sorted along a
+// Z-curve over (mx, my); the tile at position i of that order belongs to rank (i + i / world) % world. Every run of `world` consecutive
+// positions - a compact 2-D block of the image (eight ranks: 4 x 2 macro tiles) - holds each rank exactly once, and the rotation by the
+// block index keeps a rank from sitting at the same place of every block (two ranks: a checkerboard, not columns). The plain
+// `tile index % world` of rounds 1-3 gave every rank vertical 16-pixel column stripes whenever the number of tile columns was a
+// multiple of the world size (120 at 1920 px: 2, 4, 8).
+// Mirrors: parallel.tile_owner (Python), Oracle::owner_of_tile (the CPU checker).
 // Order of this rank's macro tiles: sort by (XCD chunk block, Z-curve inside the block). The 8 chunks that
 // wave_next_task hands to the 8 XCD queues are equal slices of this order, so each is a compact image block.
 void egr_build_task_order(egr_context *c) {
@@ -572,11 +582,18 @@ void egr_build_task_order(egr_context *c) {
         x = (x | (x << 8)) & 0x00FF00FFu, x = (x | (x << 4)) & 0x0F0F0F0Fu, x = (x | (x << 2)) & 0x33333333u, x = (x | (x << 1)) & 0x55555555u;
         return x;
     };
+    std::vector<std::pair<uint32_t, uint32_t>> zorder; // (Z-curve key, macro tile) of the whole image
+    zorder.reserve((size_t)mtx * mty);
+    for (uint32_t m = 0; m < mtx * mty; m++) zorder.push_back({part1by1(m % mtx) | (part1by1(m / mtx) << 1), m});
+    std::sort(zorder.begin(), zorder.end());
     std::vector<std::pair<uint64_t, uint32_t>> keyed;
-    for (uint32_t m = (uint32_t)c->rank; m < mtx * mty; m += (uint32_t)c->world) {
+    for (size_t b = 0; b * (size_t)c->world < zorder.size(); b++) { // this rank's share: one tile of every block of `world` Z-order positions
+        const size_t i = b * (size_t)c->world + (size_t)(((uint32_t)c->rank + (uint32_t)c->world - (uint32_t)(b % (size_t)c->world)) % (uint32_t)c->world);
+        if (i >= zorder.size()) continue;
+        const uint32_t m = zorder[i].second;
         const uint32_t mx = m % mtx, my = m / mtx;
         const uint32_t bx = std::min(3u, mx * 4u / mtx), by = std::min(1u, my * 2u / mty); // 4 x 2 blocks of the image
-        const uint64_t key = ((uint64_t)(by * 4u + bx) << 32) | (part1by1(mx) | (part1by1(my) << 1));
+        const uint64_t key = ((uint64_t)(by * 4u + bx) << 32) | zorder[i].first;
         keyed.push_back({key, m});
     }
     std::sort(keyed.begin(), keyed.end());
@@ -682,7 +699,7 @@ DeviceView egr_make_view(const egr_context *c) {
     return v;
 }
 
-void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
+void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s) {
     DeviceView v = egr_make_view(c);
     const dim3 block(EGR_WAVE);
     egr_stamp_begin(c, "prologue+live", s);
@@ -690,8 +707,7 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
     EGR_HIP(hipMemsetAsync(c->stats.num_accumulated_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s)); // stats.h:25-28
     EGR_HIP(hipMemsetAsync(c->stats.num_traversed_per_pixel, 0, sizeof(int32_t) * v.num_pixels, s));
     // (skipped when the egr_update_bvh_ex(EGR_UPDATE_FUSE_LIVE) just before this launch wrote the same records from the same parameters)
-    if (v.n && !c->live_fresh) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v, grads ? 1 : 0);
-    c->live_fresh = false;
+    if (v.n && !live_fresh) hipLaunchKernelGGL(k_live, dim3((v.n + 255) / 256), dim3(256), 0, s, v, grads ? 1 : 0);
     egr_stamp_end(c, s);
     if (v.num_tasks) {
         // Strands: slices of the task order (whole macro tiles), each with its own queues and scratch slots, each running its
@@ -751,13 +767,15 @@ void egr_trace_launch(egr_context *c, bool grads, hipStream_t s) {
 void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s) {
     DeviceView v = egr_make_view(c);
     const size_t bytes = (size_t)EGR_NSTEPS * v.num_pixels * sizeof(int32_t);
-    int32_t *dev = nullptr;
-    EGR_HIP(hipMalloc((void **)&dev, bytes));
-    EGR_HIP(hipMemsetAsync(dev, 0, bytes, s));
-    if (v.num_tasks) hipLaunchKernelGGL(k_export_step_hits, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev);
-    EGR_HIP(hipMemcpyAsync(host_out, dev, bytes, hipMemcpyDeviceToHost, s));
+    struct DevBuf { // freed on every way out (an EGR_HIP below may throw)
+        int32_t *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } dev;
+    EGR_HIP(hipMalloc((void **)&dev.p, bytes));
+    EGR_HIP(hipMemsetAsync(dev.p, 0, bytes, s));
+    if (v.num_tasks) hipLaunchKernelGGL(k_export_step_hits, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev.p);
+    EGR_HIP(hipMemcpyAsync(host_out, dev.p, bytes, hipMemcpyDeviceToHost, s));
     EGR_HIP(hipStreamSynchronize(s));
-    EGR_HIP(hipFree(dev));
 }
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s) {

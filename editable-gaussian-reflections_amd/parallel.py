@@ -1,8 +1,9 @@
 """Multi-GPU decomposition of the hot path (nothing like it exists in the reference).
 
 The path shards over PIXELS: forward is independent per pixel, backward contributions sum over pixels. One
-process per GPU holds the full Gaussian set + BVH and traces the 16x16-pixel macro tiles whose index is congruent
-to its rank (round-robin = load balance between empty and dense image regions); the only exchange step is ONE
+process per GPU holds the full Gaussian set + BVH and traces its share of the 16x16-pixel macro tiles: the tiles are dealt
+round-robin along a Z-curve over the image (`tile_owner`: every rank owns one tile of every compact block of `world` tiles = load
+balance between empty and dense image regions in both directions); the only exchange step is ONE
 all-reduce (sum) of the contiguous [22N] per-launch gradient buffer per iteration (RCCL over xGMI on the GPU box, gloo in the
 CPU tests). After it every rank holds identical gradients, so the replicated optimiser steps stay in lock-step.
 """
@@ -16,20 +17,44 @@ def macro_tiles(width, height):
     return (width + MACRO_TILE - 1) // MACRO_TILE, (height + MACRO_TILE - 1) // MACRO_TILE
 
 
+def _part1by1(x):
+    x = x.astype(np.uint32) & 0xFFFF
+    x = (x | (x << 8)) & 0x00FF00FF
+    x = (x | (x << 4)) & 0x0F0F0F0F
+    x = (x | (x << 2)) & 0x33333333
+    x = (x | (x << 1)) & 0x55555555
+    return x
+
+
+def tile_owner(width, height, world):
+    """[mty, mtx] int array: the rank that owns each 16x16 macro tile. Python mirror of egr_build_task_order (csrc/trace.hip): the macro
+    tiles are sorted along a Z-curve over (mx, my); the tile at position i of that order belongs to rank (i + i // world) % world -
+    every run of `world` positions (a compact 2-D block of the image) holds each rank once, rotated by the block index."""
+    mtx, mty = macro_tiles(width, height)
+    my, mx = np.meshgrid(np.arange(mty), np.arange(mtx), indexing="ij")
+    key = (_part1by1(mx) | (_part1by1(my) << 1)).reshape(-1)
+    order = np.argsort(key, kind="stable")  # (keys are distinct)
+    pos = np.empty(mtx * mty, np.int64)
+    pos[order] = np.arange(mtx * mty)
+    return ((pos + pos // world) % world).reshape(mty, mtx)
+
+
 def num_tasks_for_rank(width, height, rank, world):
     """Python mirror of egr_num_tasks_for_rank (csrc/trace.hip): wave tiles (8x8) owned by `rank`."""
-    mtx, mty = macro_tiles(width, height)
-    M = mtx * mty
-    if rank >= M:
-        return 0
-    return 4 * ((M - rank + world - 1) // world)
+    return 4 * int((tile_owner(width, height, world) == rank).sum())
 
 
 def owner_map(width, height, world):
     """[H,W] int array: which rank traces each pixel (mirror of task_geom in csrc/egr_state.hpp)."""
-    mtx, _ = macro_tiles(width, height)
+    own = tile_owner(width, height, world)
     yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
-    return ((yy // MACRO_TILE) * mtx + (xx // MACRO_TILE)) % world
+    return own[yy // MACRO_TILE, xx // MACRO_TILE]
+
+
+def rank_of_tile(width, height, world, tile_index):
+    """The rank whose partition is exactly / contains macro tile `tile_index` (= my * mtx + mx). With world = number of macro tiles
+    every rank owns one tile: tests use that to trace single tiles through the product's own partition."""
+    return int(tile_owner(width, height, world).reshape(-1)[tile_index])
 
 
 def all_reduce_flat(flat, group=None):

@@ -19,6 +19,7 @@
 #ifndef EGR_RAYTRACER_H
 #define EGR_RAYTRACER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -179,8 +180,18 @@ int egr_set_exact_stats(egr_context *ctx, int enable);
  * when the rank has at least four tiles per resident wave slot and one strand below that (multi-GPU partitions). */
 int egr_set_strands(egr_context *ctx, int strands);
 
-/* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace. */
+/* Task shape (not in the reference): pixels one wave traces together. 64 = 8x8 (default), 32 = 8x4, 16 = 4x4; 0 = automatic (64, or
+ * 32 for a rank of a partition with fewer than two 8x8 tiles per resident wave). Also settable at creation with env
+ * EGR_RAYS_PER_TASK. The ORDER of exactly tied hits of a bounce ray depends on the shape (deviation (a)); parity tests
+ * that trace single macro tiles through egr_set_partition pin the shape of the run they compare with. Returns 1 for other values. */
+int egr_set_rays_per_task(egr_context *ctx, int rays_per_task);
+
+/* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace.
+ * ABI: egr_counters only ever GROWS AT ITS END (version string of egr_version() bumps with it). egr_get_counters writes
+ * sizeof(egr_counters) of THIS header; a host compiled against an older header passes its own sizeof to egr_get_counters_ex, which
+ * writes min(out_bytes, sizeof(egr_counters)) bytes - never more than the caller's struct holds. */
 int egr_get_counters(egr_context *ctx, egr_counters *out, void *hip_stream);
+int egr_get_counters_ex(egr_context *ctx, void *out, size_t out_bytes, void *hip_stream);
 int egr_reset_lifetime_counters(egr_context *ctx, void *hip_stream);
 
 /* Wall-clock of the last egr_raytrace / egr_update_bvh on the GPU (HIP events recorded on the launch stream
