@@ -11,7 +11,7 @@ import). A "ray" = one (pixel, bounce-step) traversal; rays/step come from the k
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: the image is split into 16x16-pixel tiles dealt round-robin to the ranks (the scene and the BVH are
+Multi-GPU: the image is split into 16x16-pixel tiles dealt round-robin along a Z-curve to the ranks (the scene and the BVH are
 replicated), THIS launch's gradients are summed with ONE RCCL all-reduce of a flat [22N] buffer -> "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
@@ -27,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r3"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
+ROUND = "r4"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
 
 
 def parse():
@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--bounces", type=int, default=2)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="480x270")
+    p.add_argument("--primary-steps", type=int, default=30, help="timed iterations of the primary-only (num_bounces = 0) leg; 0 skips it")
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
     p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 3 from four tiles per wave slot, else 1); the per-kernel profile pass always uses 1")
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
@@ -167,6 +168,25 @@ def main():
         dt, total_rays = reduce_pair(dt, float(c[9]))
         res["ms_per_step"] = dt / a.steps * 1e3
         res["value"] = total_rays / dt / 1e6
+        # "report also primary-only (num_bounces = 0: exactly P rays), because bounce termination is scene dependent"
+        if a.bounces > 0 and a.primary_steps > 0:
+            m.get_config().num_bounces.fill_(0)
+            for _ in range(10):
+                one_step()
+            barrier()
+            m.reset_lifetime_counters()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(a.primary_steps):
+                one_step()
+            barrier()
+            dtp = time.perf_counter() - t0
+            dtp, rays_p = reduce_pair(dtp, float(m.get_counters()[9]))
+            res["primary_only"] = {"value": round(rays_p / dtp / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dtp / a.primary_steps * 1e3, 4), "steps": a.primary_steps,
+                                   "rays_per_step": int(rays_p / a.primary_steps), "note": "num_bounces = 0: one ray per pixel, same iteration otherwise"}
+            m.get_config().num_bounces.fill_(a.bounces)
+            for _ in range(5):
+                one_step()
 
         cpu = None
         if with_cpu and rank == 0 and world == 1:  # reported at N=1 only (the other ranks would sit in the next collective meanwhile)
@@ -236,17 +256,14 @@ def main():
             cands = {"forward_chain": fwd_ref}
             if not a.forward_only:
                 cands["backward_chain"] = sum(algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank) for s in range(3))
-            dom = max((k for k in cands if k in kern), key=lambda k: kern[k])
-            # the two chains of the dense-init cloud take the same time to within run-to-run noise (4.7 ms each): the forward chain - the
-            # traversal kernel the north star's roofline target speaks of - stays the reported one unless the backward chain is clearly longer
-            if dom == "backward_chain" and kern["backward_chain"] <= 1.1 * kern.get("forward_chain", 0.0):
-                dom = "forward_chain"
+            dom = max((k for k in cands if k in kern), key=lambda k: kern[k])  # the longest kernel of the launch IS the reported one
             # HBM traffic per kernel: rocprofv3 --pmc passes of THIS workload collected in THIS round by tools/profile.sh (separate
             # FETCH_SIZE / WRITE_SIZE passes; units of KiB; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md) and committed
             # as profiles/<round>/pmc_summary.json, keyed by workload. bench.py cannot run the profiler around itself.
-            pmc = {}
+            pmc, pmc_round = {}, ROUND
             try:
-                pj = os.path.join(ROOT, "profiles", ROUND, "pmc_summary.json")
+                pmc_round = next((r for r in (ROUND, "r3") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_summary.json"))), ROUND)  # (this round's passes once they are committed; the traffic source names the round)
+                pj = os.path.join(ROOT, "profiles", pmc_round, "pmc_summary.json")
                 if os.path.exists(pj) and world == 1 and a.emulate_world <= 1 and N == (100_000 if a.config == "B" else 1_000_000) and (W, H) == (1920, 1080):
                     pmc = json.load(open(pj)).get(f"{a.config}_{variant}", {})
             except Exception:
@@ -257,8 +274,8 @@ def main():
                 pm, traffic, src = pmc.get(k), None, None
                 if pm and "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                     traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                    src = f"profiles/{ROUND}/pmc_summary.json[{a.config}_{variant}] (rocprofv3 --pmc, this round, same workload; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
-                r = {"bound": "hbm", "kernel": k, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                    src = f"profiles/{pmc_round}/pmc_summary.json[{a.config}_{variant}] (rocprofv3 --pmc passes of round {pmc_round}, same workload; 2 x FETCH_SIZE + WRITE_SIZE per launch)"
+                r = {"bound": "hbm", "kernel": k, "longest_kernel_of_the_launch": k == dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
                      "traffic": traffic, "traffic_over_algorithmic": round(traffic / cands[k], 3) if traffic else None, "traffic_source": src,
                      "avg_kernel_ms": round(kern[k], 4), "algorithmic_bytes_per_launch": cands[k]}
                 if k == "backward_chain":
@@ -295,7 +312,7 @@ def main():
         ov = "init" if a.variant == "trained" else "trained"
         r2 = run_variant(ov, True, False)
         other = {"variant": ov, "value": round(r2["value"], 3), "unit": "Mrays/s", "ms_per_step": round(r2["ms_per_step"], 4), "status": r2["status"],
-                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"], "device_bytes": r2.get("device_bytes")}
+                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"], "device_bytes": r2.get("device_bytes"), "primary_only": r2.get("primary_only")}
     if rank == 0:
         line = {
             "metric": "Mrays/s fwd+bwd @1080p, 1M Gaussians" if a.config == "C" and not a.forward_only else "Mrays/s fwd-only @1080p",
@@ -306,6 +323,7 @@ def main():
                                    f"the other variant is in `other_variant`), N={N}, {W}x{H}, {what}, num_bounces={a.bounces}, jitter on, reference default config",
                        "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients"},
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"], "kernel_ms": main_res["kernel_ms"],
+            "value_primary_only": (main_res.get("primary_only") or {}).get("value"), "primary_only": main_res.get("primary_only"),
             "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None, "device_bytes": main_res.get("device_bytes"),
             vkey[a.variant]: round(main_res["value"], 3), vkey["init" if a.variant == "trained" else "trained"]: (other or {}).get("value"),
             "note": "vs_baseline null: the reference publishes no throughput number; PSNR vs OptiX is unmeasurable here (no NVIDIA "

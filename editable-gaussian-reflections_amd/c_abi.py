@@ -63,6 +63,7 @@ def lib(path=None):
         L.egr_update_bvh_ex.argtypes = [P, C.c_uint, P]
         L.egr_set_partition.argtypes = [P, C.c_int, C.c_int]
         L.egr_set_exact_stats.argtypes = [P, C.c_int]
+        L.egr_set_grad_overwrite.argtypes = [P, C.c_int]
         L.egr_set_strands.argtypes = [P, C.c_int]
         L.egr_set_rays_per_task.argtypes = [P, C.c_int]
         L.egr_get_counters.argtypes = [P, C.POINTER(egr_counters), P]

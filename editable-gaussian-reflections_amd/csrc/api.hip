@@ -114,6 +114,12 @@ int egr_set_partition(egr_context *c, int rank, int world) {
     return guarded(c, [&] { egr_build_task_order(c); }); // cached per (rank, world): flipping between two partitions costs nothing
 }
 
+int egr_set_grad_overwrite(egr_context *c, int enable) {
+    if (!c) return 1;
+    c->grad_overwrite = enable != 0;
+    return 0;
+}
+
 int egr_set_exact_stats(egr_context *c, int enable) {
     if (!c) return 1;
     c->live_fresh = false;

@@ -98,6 +98,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t task_begin, task_count; // this strand's slice of the rank's task order (see egr_trace_launch)
     uint32_t *queues;      // [strands][2 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
+    int grad_overwrite;    // k_grad_gather stores this launch's sums (per-launch buffer, egr_set_grad_overwrite) instead of adding them
     int cube_mode;         // exact-statistics launch (egr_set_exact_stats): the tree bounds instance CUBES, every overlap is counted
 };
 
@@ -165,6 +166,7 @@ struct egr_context {
     float *cand_keys = nullptr;
     float2 *cand_vals = nullptr;
     uint32_t *stack_spill = nullptr;
+    bool grad_overwrite = false;  // egr_set_grad_overwrite
     bool exact_stats = false;     // egr_set_exact_stats: cube boxes + reference-defined candidate count (takes effect at the next update / rebuild)
     bool boxes_are_cubes = false; // what the current tree was refitted with
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final

@@ -218,10 +218,11 @@ struct GaussianDataHolder : torch::CustomClassHolder {
         roughness.mutable_grad() = dL_droughness, opacity.mutable_grad() = dL_dopacity, scale.mutable_grad() = dL_dscale;
         mean.mutable_grad() = dL_dmean, rotation.mutable_grad() = dL_drotation;
     }
-    // Multi-GPU (not in the reference): with `use_delta` the kernels accumulate THIS launch's gradients and weights into a zeroed
-    // [22N] buffer of their own (grad_delta) instead of the persistent one, so the caller can all-reduce exactly one launch's
-    // contribution and then fold it in (renderer.py: all_reduce_grads) - summing the persistent buffer would multiply whatever it
-    // already holds (total_weight across a pruning interval, accumulated gradients) by the world size on every iteration.
+    // Multi-GPU (not in the reference): with `use_delta` a grad launch STORES its gradients and weights in a [22N] buffer of its own
+    // (grad_delta; egr_set_grad_overwrite: rows no ray touched read 0, nobody has to clear it) instead of adding them to the persistent
+    // one, so the caller can all-reduce exactly one launch's contribution and then fold it in (renderer.py: all_reduce_grads) - summing
+    // the persistent buffer would multiply whatever it already holds (total_weight across a pruning interval, accumulated gradients)
+    // by the world size on every iteration.
     Tensor grad_delta = torch::empty({0}, F32());
     bool use_delta = false;
     void set_use_delta(bool on) {
@@ -399,6 +400,7 @@ struct Raytracer : torch::CustomClassHolder {
         gaussian_data->set_use_delta(on);
         egr_gaussians g = gaussian_data->reify();
         check(egr_set_gaussians(ctx, &g), "use_grad_delta");
+        check(egr_set_grad_overwrite(ctx, on ? 1 : 0), "use_grad_delta"); // a grad launch STORES its sums in grad_delta: nobody clears it
     }
     // exact statistics: num_traversed_per_pixel / the candidate counters become the reference's intersection-program invocation
     // count (cube boxes, slower). Takes effect with the next update_bvh() / rebuild_bvh(); raytrace() refuses to run in between.

@@ -453,7 +453,9 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
 
 // Last backward kernel: one thread per gaussian id adds its gradient row (a 128-B line at its record position) to the
 // caller's gradient tensors - coalesced on the tensor side - and empties the row for the next launch.
-__global__ void __launch_bounds__(256) k_grad_gather(DeviceView v) {
+// OVERWRITE (egr_set_grad_overwrite: the tensors are a per-launch buffer that is all-reduced over the ranks): the launch's sums are
+// STORED, rows without a contribution store zeros - the caller neither clears the buffer nor pays the read half of a "+=".
+template <bool OVERWRITE> __global__ void __launch_bounds__(256) k_grad_gather(DeviceView v) {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= v.n) return;
     float4 *row = reinterpret_cast<float4 *>(v.grad_rows + (size_t)v.pos_of_gid[gid] * EGR_ROW_STRIDE);
@@ -465,20 +467,26 @@ __global__ void __launch_bounds__(256) k_grad_gather(DeviceView v) {
         x[4 * q] = r.x, x[4 * q + 1] = r.y, x[4 * q + 2] = r.z, x[4 * q + 3] = r.w;
         any |= (f2u(r.x) | f2u(r.y) | f2u(r.z) | f2u(r.w)) << 1; // ignore the sign bit: -0 is empty too
     }
-    if (any == 0) return;
+    if (!OVERWRITE && any == 0) return;
+    if (any != 0) {
 #pragma unroll
-    for (int q = 0; q < 6; q++) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 6; q++) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const egr_gaussians &g = v.g;
-    g.dL_dopacity[gid] += x[GC_OPA];
+    auto put = [](float *p, float val) {
+        if (OVERWRITE) *p = val;
+        else *p += val;
+    };
+    put(g.dL_dopacity + gid, x[GC_OPA]);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        g.dL_dscale[3 * gid + a] += x[GC_SCALE + a], g.dL_dmean[3 * gid + a] += x[GC_MEAN + a], g.dL_drgb[3 * gid + a] += x[GC_RGB + a];
-        g.dL_dnormal[3 * gid + a] += x[GC_NORMAL + a], g.dL_df0[3 * gid + a] += x[GC_F0 + a];
+        put(g.dL_dscale + 3 * gid + a, x[GC_SCALE + a]), put(g.dL_dmean + 3 * gid + a, x[GC_MEAN + a]), put(g.dL_drgb + 3 * gid + a, x[GC_RGB + a]);
+        put(g.dL_dnormal + 3 * gid + a, x[GC_NORMAL + a]), put(g.dL_df0 + 3 * gid + a, x[GC_F0 + a]);
     }
 #pragma unroll
-    for (int a = 0; a < 4; a++) g.dL_drotation[4 * gid + a] += x[GC_ROT + a];
-    g.dL_droughness[gid] += x[GC_ROUGH];
-    g.total_weight[gid] += x[GC_WEIGHT];
+    for (int a = 0; a < 4; a++) put(g.dL_drotation + 4 * gid + a, x[GC_ROT + a]);
+    put(g.dL_droughness + gid, x[GC_ROUGH]);
+    put(g.total_weight + gid, x[GC_WEIGHT]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -696,6 +704,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.cube_mode = c->exact_stats ? 1 : 0;
+    v.grad_overwrite = c->grad_overwrite ? 1 : 0;
     return v;
 }
 
@@ -755,11 +764,12 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
                 EGR_HIP(hipStreamWaitEvent(s, c->ev_join[st], 0));
             }
         }
-        if (grads && v.n) {
-            egr_stamp_begin(c, "backward_grad_gather", s);
-            hipLaunchKernelGGL(k_grad_gather, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
-            egr_stamp_end(c, s);
-        }
+    }
+    if (grads && v.n && (v.num_tasks || c->grad_overwrite)) { // (a rank without tiles still owes its per-launch buffer a row of zeros)
+        egr_stamp_begin(c, "backward_grad_gather", s);
+        if (c->grad_overwrite) hipLaunchKernelGGL(k_grad_gather<true>, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL(k_grad_gather<false>, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
+        egr_stamp_end(c, s);
     }
     hipLaunchKernelGGL(k_epilogue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
 }

@@ -10,6 +10,8 @@ CPU tests). After it every rank holds identical gradients, so the replicated opt
 import numpy as np
 
 MACRO_TILE = 16  # must match EGR_MACRO_TILE in csrc/egr_internal.hpp
+REDUCE_AT_WORLD_1 = False  # True: the collectives also run in a one-rank group (tests/rccl_worker.py: RCCL initialisation, the all-reduce on the
+                           # device buffer and its stream ordering against the launch are then exercised on a one-GPU box)
 WAVE_TILE = 8
 
 
@@ -63,7 +65,7 @@ def all_reduce_flat(flat, group=None):
     RCCL refuses duplicate devices) a device buffer is staged through the host."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or REDUCE_AT_WORLD_1):
         if flat.is_cuda and dist.get_backend(group) == "gloo":
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -74,15 +76,58 @@ def all_reduce_flat(flat, group=None):
 
 
 def all_reduce_launch_delta(grad_flat, grad_delta, group=None):
-    """The exchange step of one training iteration: `grad_delta` holds what THIS launch added on this rank (the kernels
-    accumulate into it instead of `grad_flat`, csrc/torch_binding.cpp: GaussianDataHolder::grad_delta). Sum it over the
-    ranks with one collective, fold it into the persistent buffer, empty it for the next launch. Reducing `grad_flat`
-    itself would multiply everything it already holds - total_weight since the last prune, gradients of an earlier
-    launch that were not zeroed - by the world size each time."""
+    """The exchange step of one training iteration: `grad_delta` holds what THIS launch produced on this rank (the launch STORES
+    its sums there instead of adding to `grad_flat`: csrc/torch_binding.cpp GaussianDataHolder::grad_delta, egr_set_grad_overwrite -
+    the buffer needs no clearing between launches). Sum it over the ranks with one collective and fold it into the persistent
+    buffer: two passes over [22N] per iteration besides the collective (round 3: four - add, clear, and the read half of the
+    launch's "+="). Reducing `grad_flat` itself would multiply everything it already holds - total_weight since the last prune,
+    gradients of an earlier launch that were not zeroed - by the world size each time."""
     all_reduce_flat(grad_delta, group)
     grad_flat.add_(grad_delta)
-    grad_delta.zero_()
     return grad_flat
+
+
+class ImageGather:
+    """Evaluation renders of a partitioned tracer ("framebuffer outputs are all-gathered only for evaluation renders").
+    Under no_grad every rank traces ITS OWN tiles; `gather` then completes the listed [S,H,W,C] buffers on every rank with ONE
+    all-gather of the packed pixels of each rank (copies only: the assembled image equals a whole-image render bit for bit).
+    Per frame and rank at 1080p, all ten output buffers: 62 MB sent, 436 MB received at world 8 (the six buffers render() returns:
+    37 / 261 MB)."""
+
+    def __init__(self, width, height, rank, world, device):
+        import torch
+
+        own = owner_map(width, height, world).reshape(-1)
+        self.rank, self.world = rank, world
+        idx = [np.flatnonzero(own == r) for r in range(world)]
+        self.count = [len(i) for i in idx]
+        self.pad = max(self.count)
+        self.idx = [torch.as_tensor(i, dtype=torch.long, device=device) for i in idx]
+
+    def gather(self, buffers, group=None):
+        import torch
+        import torch.distributed as dist
+
+        views = [b.view(b.shape[0], -1, b.shape[-1]) for b in buffers]  # [S, P, C]
+        mine = self.idx[self.rank]
+        parts = [v[:, mine, :].reshape(-1) for v in views]
+        per_pixel = sum(v.shape[0] * v.shape[2] for v in views)
+        send = torch.zeros(self.pad * per_pixel, dtype=buffers[0].dtype, device=buffers[0].device)
+        send[: self.count[self.rank] * per_pixel] = torch.cat(parts)
+        host = send.is_cuda and dist.get_backend(group) == "gloo"  # (two test ranks sharing one GPU: staged through the host)
+        if host:
+            send = send.cpu()
+        recv = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(recv, send, group=group)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            chunk, off, n = recv[r].to(buffers[0].device) if host else recv[r], 0, self.count[r]
+            for v in views:
+                sz = v.shape[0] * n * v.shape[2]
+                v[:, self.idx[r], :] = chunk[off:off + sz].view(v.shape[0], n, v.shape[2])
+                off += sz
+        return buffers
 
 
 GRAD_LAYOUT = [("dL_drgb", 3), ("dL_dnormal", 3), ("dL_df0", 3), ("dL_droughness", 1), ("dL_dopacity", 1), ("dL_dscale", 3),

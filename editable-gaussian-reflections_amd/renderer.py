@@ -7,9 +7,10 @@ passed unchanged: pose conversion R_blender = -R with column 0 re-negated, set_p
 fov = FoVy, ZNEAR/ZFAR env overrides, export order, targets CHW -> HWC, zero targets when absent, update_bvh iff
 grad mode or forced, raytrace, optional denoise, gradient import by add_.
 
-Additions for the MI355X build: `rank` / `world_size` (image-tile partition) and
-`all_reduce_grads()` which sums THIS launch's [22N] gradient contribution over ranks with ONE RCCL all-reduce
-(`parallel.all_reduce_launch_delta`) and folds it into the persistent gradient buffer.
+Additions for the MI355X build: `rank` / `world_size` (image-tile partition), `all_reduce_grads()` which sums
+THIS launch's [22N] gradient contribution over ranks with ONE RCCL all-reduce (`parallel.all_reduce_launch_delta`) and folds it
+into the persistent gradient buffer, and `gather_outputs()` which completes the images of a partitioned no-grad render on every
+rank with one all-gather (`parallel.ImageGather`).
 """
 import os
 from types import SimpleNamespace
@@ -18,7 +19,7 @@ import numpy as np
 import torch
 
 from . import make_raytracer
-from .parallel import all_reduce_launch_delta
+from .parallel import ImageGather, all_reduce_launch_delta
 
 
 class GaussianParams:
@@ -75,8 +76,18 @@ class GaussianParams:
 
 
 class GaussianRaytracer:
-    def __init__(self, pc, image_width: int, image_height: int, ppll_forward_size=None, ppll_backward_size=None, rank=0, world_size=1):
+    OUTPUT_BUFFERS = ("output_rgb", "output_depth", "output_normal", "output_f0", "output_roughness", "output_transmittance",
+                      "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final")
+
+    def __init__(self, pc, image_width: int, image_height: int, ppll_forward_size=None, ppll_backward_size=None, rank=0, world_size=1,
+                 gather_buffers=None):
         self.image_width, self.image_height = image_width, image_height
+        # partitioned evaluation renders: which framebuffer outputs `gather_outputs` completes on every rank (default: all ten) and
+        # whether every no-grad call does it (False: the caller gathers when it needs the images, e.g. once after the 128 accumulated
+        # samples of render.py:195-204 - the accumulators of a rank's own pixels live on that rank)
+        self.gather_buffers = tuple(gather_buffers) if gather_buffers is not None else self.OUTPUT_BUFFERS
+        self.gather_each_render = True
+        self._image_gather = None
         kw = {}
         if ppll_forward_size is not None:
             kw["ppll_forward_size"] = int(ppll_forward_size)
@@ -135,19 +146,38 @@ class GaussianRaytracer:
     @torch.no_grad()
     def all_reduce_grads(self):
         """Multi-GPU exchange step: the launch accumulated this rank's gradients + weights into the zeroed
-        per-launch buffer `grad_delta` ([22N], 88 MB at N=1M); ONE all-reduce sums it over the ranks, then it is added to
-        the persistent `grad_flat` (whose total_weight tail lives across a whole pruning interval) and emptied. No-op when
-        the tracer is not partitioned."""
+        per-launch buffer `grad_delta` ([22N], 88 MB at N=1M; the launch stores, nobody clears it); ONE all-reduce sums it over
+        the ranks, then it is added to the persistent `grad_flat` (whose total_weight tail lives across a whole pruning
+        interval). No-op when the tracer is not partitioned."""
         g = self.cuda_module.get_gaussians()
         if g.grad_delta.numel():
             all_reduce_launch_delta(g.grad_flat, g.grad_delta)
 
+    def _partitioned_eval(self):
+        """Evaluation (no-grad) renders of a partitioned tracer: with a process group every rank traces its own tiles and the images are
+        all-gathered (`gather_outputs`); without one (a single process driving one "rank" of a partition, as tools and tests do) there
+        is nobody to gather from, and the rank traces the whole image itself."""
+        import torch.distributed as dist
+
+        return self.world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world_size
+
     def _set_full_image(self, full):
-        """No-grad renders produce images: a partitioned tracer then traces the WHOLE image on every rank (each rank would
-        otherwise only write the pixels of its own tiles and hand back stale data for the rest). The library caches the tile order
-        of every partition it has seen, so the flip is a pointer swap: no device sync, no upload."""
+        """Whole-image no-grad render on a partitioned tracer (no process group, see _partitioned_eval). The library caches the tile
+        order of every partition it has seen, so the flip is a pointer swap: no device sync, no upload."""
         if self.world_size > 1:
             self.cuda_module.set_partition(0 if full else self.rank, 1 if full else self.world_size)
+
+    @torch.no_grad()
+    def gather_outputs(self, names=None):
+        """Completes the framebuffer outputs `names` (default: self.gather_buffers) of the last partitioned no-grad render on every rank:
+        one all-gather of each rank's own pixels, bit-identical to a whole-image render. The per-pixel statistics and
+        random_seeds stay per rank. No-op for an unpartitioned tracer."""
+        if not self._partitioned_eval():
+            return
+        fb = self.cuda_module.get_framebuffer()
+        if self._image_gather is None:
+            self._image_gather = ImageGather(self.image_width, self.image_height, self.rank, self.world_size, fb.output_rgb.device)
+        self._image_gather.gather([getattr(fb, n) for n in (names or self.gather_buffers)])
 
     @staticmethod
     def blender_rotation(R):
@@ -179,13 +209,16 @@ class GaussianRaytracer:
         if grads or force_update_bvh:
             # raytrace() follows with the same parameter values: one pass over the cloud writes the snapshot AND the live records
             self.cuda_module.update_bvh(True)
-        if not grads:
+        gathered = not grads and self._partitioned_eval()
+        if not grads and not gathered:
             self._set_full_image(True)
         try:
             self.cuda_module.raytrace()
         finally:  # a raytrace that raises (stale BVH, exact-stats gate) must not leave a training rank tracing the whole image
-            if not grads:
+            if not grads and not gathered:
                 self._set_full_image(False)
+        if gathered and (self.gather_each_render or denoise):
+            self.gather_outputs()  # every rank now holds the whole image (the denoiser needs it)
         if denoise:
             self.cuda_module.denoise()
         if grads:

@@ -164,6 +164,13 @@ int egr_denoise(egr_context *ctx, void *hip_stream);
  * macro tiles with (tile_index % world_size) == rank; default rank 0 of 1 = whole image. */
 int egr_set_partition(egr_context *ctx, int rank, int world_size);
 
+/* Per-launch gradient buffers (not in the reference; the multi-GPU exchange step). The reference's launch ADDS to the
+ * gradient tensors (atomicAdd, backward_pass.cu:210-220) and so does this library by default. With enable != 0 the dL_d* / total_weight
+ * pointers of egr_set_gaussians are taken as a PER-LAUNCH buffer: every grad launch STORES this launch's sums there (rows no ray
+ * touched read 0), so the caller can all-reduce the buffer over the ranks and add it to its persistent gradients without clearing it
+ * in between (one write pass over [22N] instead of a read-modify-write, and no memset per iteration). */
+int egr_set_grad_overwrite(egr_context *ctx, int enable);
+
 /* Exact statistics (not in the reference). By default the tree bounds each Gaussian's ELLIPSOID and the walk evaluates only the
  * instances whose response point can be accepted, so stats.num_traversed_per_pixel and egr_counters.candidates count the records
  * the walk EVALUATED (ellipsoid-box overlaps whose response point lies on the walked segment) - not the reference's

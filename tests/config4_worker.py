@@ -86,7 +86,6 @@ for it in range(1, ITERS + 1):
     e_grad_twin, w_out_twin = rel(gt.grad_flat[: 21 * n], gf.grad_flat[: 21 * n]), outliers(gt.total_weight, gf.total_weight)
     g_out, g_out_twin = outliers(gp.grad_flat[: 21 * n], gf.grad_flat[: 21 * n]), outliers(gt.grad_flat[: 21 * n], gf.grad_flat[: 21 * n])
     assert part.m.get_counters()[11] == 0 and full.m.get_counters()[11] == 0, (it, part.m.get_counters()[11], full.m.get_counters()[11])
-    assert float(gp.grad_delta.abs().max()) == 0.0
     pruned = 0
     if it % INTERVAL == 0:  # train.py:238-245
         wf = gf.total_weight / INTERVAL
@@ -163,7 +162,9 @@ mse, mse_twin = float(((ip - iff) ** 2).mean()), float(((itw - iff) ** 2).mean()
 # next to the partitioned run's, the bar is an absolute 30 dB: heavy-tailed, a ratio of two such numbers means nothing)
 if rank == 0:
     print("CONFIG4 evaluation render: mse partitioned vs single-rank", mse, "twin vs single-rank", mse_twin, flush=True)
-assert part.m.get_counters()[0] == W * H and mse < 1e-3, (mse, mse_twin)
+rays_part = torch.tensor([float(part.m.get_counters()[0])], dtype=torch.float64)
+dist.all_reduce(rays_part)  # every rank traced its own tiles, the images were all-gathered (renderer.gather_outputs)
+assert int(rays_part.item()) == W * H and part.m.get_counters()[0] < W * H and mse < 1e-3, (mse, mse_twin)
 dist.barrier()
 if rank == 0:
     print("CONFIG4_OK", log[-1], flush=True)

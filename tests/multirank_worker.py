@@ -44,7 +44,9 @@ for it in range(3):  # three training iterations; total_weight is only cleared a
     err = float((a[: 21 * N] - b[: 21 * N]).abs().max()) / scale
     werr = float((a[21 * N:] - b[21 * N:]).abs().max()) / float(b[21 * N:].abs().max())
     assert err < 1e-5 and werr < 1e-5, (it, err, werr)  # summed over ranks == single rank, weights grow linearly (not x world per iteration)
-    assert float(gp.grad_delta.abs().max()) == 0.0
+    # the per-launch buffer holds the SUM over the ranks of this launch (stored by the launch, reduced in place, never cleared)
+    derr = float((gp.grad_delta[: 21 * N] - b[: 21 * N]).abs().max()) / scale
+    assert derr < 1e-5, (it, derr)
     # the model-side gradients (python import) agree too
     perr = float((part.pc._xyz.grad - full.pc._xyz.grad).abs().max()) / float(full.pc._xyz.grad.abs().max())
     assert perr < 1e-5, perr
@@ -55,14 +57,42 @@ cp, cf = part.cuda_module.get_counters(), full.cuda_module.get_counters()
 rays = torch.tensor([float(cp[0])], dtype=torch.float64)
 dist.all_reduce(rays)
 assert int(rays.item()) == cf[0] == W * H and cp[11] == 0 and cf[11] == 0
-# evaluation renders of a partitioned tracer hand back WHOLE images on every rank
+# evaluation renders of a partitioned tracer: every rank traces ITS tiles, one all-gather completes the images on every rank -
+# bit for bit the whole-image render of the unpartitioned tracer, all ten output buffers
+def same_images(tag):
+    fp, ff = part.cuda_module.get_framebuffer(), full.cuda_module.get_framebuffer()
+    for name in ren.GaussianRaytracer.OUTPUT_BUFFERS:
+        assert torch.equal(getattr(fp, name), getattr(ff, name)), (tag, name)
 with torch.no_grad():
     for rt in (part, full):
         rt.cuda_module.get_metadata().total_num_calls.zero_()
         rt(camera)
-ip, iff = part.cuda_module.get_framebuffer().output_final, full.cuda_module.get_framebuffer().output_final
-assert torch.equal(ip, iff)
-assert part.cuda_module.get_counters()[0] == W * H
+same_images("one sample")
+rays = torch.tensor([float(part.cuda_module.get_counters()[0])], dtype=torch.float64)
+dist.all_reduce(rays)
+assert int(rays.item()) == W * H and part.cuda_module.get_counters()[0] < W * H  # nobody traced the whole image
+# render.py:195-209: accumulated samples (jitter on), the gather deferred to the end of the loop, then the denoiser on the whole image
+for rt in (part, full):
+    rt.cuda_module.get_config().jitter_primary_rays.fill_(True)
+    rt.cuda_module.get_config().accumulate_samples.fill_(True)
+    rt.cuda_module.reset_accumulators()
+    rt.cuda_module.get_metadata().total_num_calls.zero_()
+part.gather_each_render = False
+with torch.no_grad():
+    for _ in range(4):
+        for rt in (part, full):
+            ren.render(camera, rt)
+part.gather_outputs()
+same_images("four accumulated samples, one gather")
+part.gather_each_render = True
+with torch.no_grad():
+    for rt in (part, full):
+        pk = ren.render(camera, rt, denoise=True)
+same_images("fifth sample")
+assert torch.equal(part.cuda_module.get_framebuffer().output_denoised, full.cuda_module.get_framebuffer().output_denoised)
+for rt in (part, full):
+    rt.cuda_module.get_config().jitter_primary_rays.fill_(False)
+    rt.cuda_module.get_config().accumulate_samples.fill_(False)
 part.zero_grad()
 ren.render(camera, part)  # and the next training iteration is partitioned again
 assert part.cuda_module.get_counters()[0] == cp[0]

@@ -24,6 +24,16 @@ def test_two_ranks_on_one_gpu_sum_to_the_single_rank_gradients():
     assert r.returncode == 0 and "MULTIRANK_OK" in r.stdout, r.stdout[-4000:]
 
 
+@pytest.mark.timeout(600)
+def test_exchange_step_through_rccl_at_world_size_1():
+    """RCCL itself (backend "nccl"): communicator initialisation, the all-reduce on the device-resident per-launch buffer behind the
+    launch on torch's stream, the fold, the import, and the evaluation all-gather, on a one-rank group (the box has one GPU)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env,
+                       timeout=540, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-4000:]
+
+
 @pytest.mark.timeout(900)
 def test_bench_two_ranks_prints_one_line():
     """bench.py under torch.distributed.run exactly as the driver launches it (reduced sizes, gloo because both ranks sit on cuda:0)."""

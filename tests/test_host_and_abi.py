@@ -107,9 +107,22 @@ def test_tile_partition_covers_image_once():
             assert own.min() == 0 and own.max() <= world - 1
             mtx, mty = par.macro_tiles(W, H)
             assert sum(par.num_tasks_for_rank(W, H, r, world) for r in range(world)) == 4 * mtx * mty
-            if world == 8 and W == 1920:  # balanced within one macro tile row
+            tiles = par.tile_owner(W, H, world)
+            for r in range(world):
+                assert par.num_tasks_for_rank(W, H, r, world) == 4 * int((tiles == r).sum())
+            cnt = np.bincount(tiles.ravel(), minlength=world)
+            assert cnt.max() - cnt.min() <= 1  # dealt round-robin
+            if world == 8 and W == 1920:
                 counts = np.bincount(own.ravel(), minlength=world)
                 assert counts.max() - counts.min() <= 16 * 16 * 2
+                # a 2-D lattice, not column stripes (round 3: tile index % world = every 8th 16-pixel column): every rank owns tiles in
+                # (nearly) every tile column AND every tile row, and every aligned 4 x 2 block of macro tiles holds all eight ranks
+                for r in range(world):
+                    ys, xs = np.nonzero(tiles == r)
+                    assert len(set(xs)) >= mtx // 4 and len(set(ys)) >= mty // 2, (r, len(set(xs)), len(set(ys)))
+                assert all(len(set(tiles[y:y + 2, x:x + 4].ravel())) == 8 for y in range(0, 64, 2) for x in range(0, 64, 4))
+            if world == 2 and W == 1920:  # a checkerboard
+                assert np.all(tiles[:64, :64] == (np.add.outer(np.arange(64), np.arange(64)) & 1) ^ tiles[0, 0])
 
 
 def test_synthetic_scene_is_deterministic_and_well_formed(syn):
@@ -147,12 +160,19 @@ for it in range(3):                       # three training iterations with a zer
     delta, out = run(rank, world)         # this rank's tiles only -> the per-launch buffer (grad_delta)
     assert np.all(out["output_final"][0][own != rank] == 0)  # untouched pixels
     par.all_reduce_launch_delta(persistent, delta)   # the ONE exchange step, the product's own helper (renderer.all_reduce_grads)
-    assert float(delta.abs().max()) == 0.0           # emptied for the next launch
+    assert float((delta - full).abs().max()) < 1e-12 * float(full.abs().max())  # the per-launch buffer now holds the sum over the ranks
     err = float((persistent[: 21 * N] - full[: 21 * N]).abs().max() / full.abs().max())
     assert err < 1e-12, (it, err)
     werr = float((persistent[21 * N:] - (it + 1) * full[21 * N:]).abs().max() / full[21 * N:].abs().max())
     assert werr < 1e-12, (it, werr)       # total_weight = sum over iterations, NOT multiplied by the world size each time
     persistent[: 21 * N].zero_()          # GaussianRaytracer.zero_grad keeps total_weight
+# evaluation renders (SURVEY 8e): every rank holds its own pixels of the [S,H,W,C] buffers, one all-gather completes them everywhere
+torch.manual_seed(7)
+whole = [torch.randn(3, H, W, 3, dtype=torch.float64), torch.randn(3, H, W, 1, dtype=torch.float64), torch.randn(1, H, W, 3, dtype=torch.float64)]
+mask = torch.from_numpy(own == rank)
+mine = [torch.where(mask[None, :, :, None], b, torch.full_like(b, float("nan"))) for b in whole]  # the other ranks' pixels: stale garbage
+par.ImageGather(W, H, rank, world, "cpu").gather(mine)
+assert all(torch.equal(a, b) for a, b in zip(mine, whole))
 views = par.split_flat(persistent, N)
 assert views["dL_drotation"].shape == (N, 4) and views["total_weight"].shape == (N, 1)
 if rank == 0: print("GLOO_OK", err, werr)

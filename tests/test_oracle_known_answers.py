@@ -371,3 +371,38 @@ def test_pixel_mask_and_per_step_counts(orc, syn):
     for k in ("dL_dmean", "dL_drgb", "dL_dopacity", "dL_drotation", "total_weight"):
         s = parts[0][k] + parts[1][k]
         assert np.abs(s - full[k]).max() <= 1e-12 * np.abs(full[k]).max(), k
+
+
+def _scaling_rotation_scene():
+    """Gaussians from the reference-generated fixture (tests/golden/make_rotation_vectors.py): raw quaternions and activated scales fed
+    through the reference's build_scaling_rotation (utils/general_utils.py:79-113) -> L = R . diag(s)."""
+    z = np.load(os.path.join(GOLD, "reference_scaling_rotation.npz"))
+    n = z["rotation_raw"].shape[0]
+    rng = np.random.default_rng(3)
+    o_act = 0.6
+    g = dict(rgb=np.full((n, 3), 0.5, np.float32), normal=np.tile(np.float32([[0, 0, 1]]), (n, 1)), f0=np.full((n, 3), 0.04, np.float32),
+             roughness=np.full((n, 1), 0.3, np.float32), opacity=np.full((n, 1), math.log(o_act / (1 - o_act)), np.float32),
+             scale=np.log(z["scaling"]).astype(np.float32), mean=rng.uniform(-1, 1, (n, 3)).astype(np.float32), rotation=z["rotation_raw"].astype(np.float32))
+    o32 = np.float32(1.0) / (np.float32(1.0) + np.exp(-g["opacity"][0, 0]))
+    sigma = float((6.0 * math.log(float(o32) / 0.005)) ** (1.0 / 6.0))  # kernel.cu:3-6, exp_power 3, alpha_threshold 0.005
+    return g, z, sigma
+
+
+def test_instance_transform_matches_the_reference_build_scaling_rotation(orc):
+    """K1 pinned by reference OUTPUT: the 3x3 part of the instance transform the oracle builds (optix/bvh_wrapper.cu:9-31,49-53:
+    M = R(q) . diag(exp(scale) * sigma * g)) equals sigma * g times the reference's own build_scaling_rotation(exp(scale), q) - the (r, x, y, z)
+    quaternion order, the normalisation and the row / column convention are the reference's, not this build's reading of them."""
+    g, z, sigma = _scaling_rotation_scene()
+    for gsf in (1.0, 1.7):
+        o = orc.Oracle(8, 8)
+        o.set_config(global_scale_factor=gsf)
+        o.set_gaussians(g)
+        o.update_bvh()
+        M, Wm, _, vis = o.instances()
+        assert vis.all()
+        L = z["L"].astype(np.float64) * sigma * gsf
+        assert np.abs(M[:, :, :3] - L).max() <= 4e-6 * np.abs(L).max(), np.abs(M[:, :, :3] - L).max()
+        np.testing.assert_allclose(M[:, :, 3], g["mean"], rtol=0, atol=0)
+        # W = M^-1 (what OptiX derives): W3x3 . L = identity
+        prod = np.einsum("nij,njk->nik", Wm[:, :, :3], L)
+        assert np.abs(prod - np.eye(3)).max() < 2e-5
