@@ -104,26 +104,32 @@ EGR_DI f3 primary_direction(const DeviceView &v, int ix, int iy, bool jitter, ui
     return normalize(w0 * x + w1 * y - w2);
 }
 
-// Object-space quantities of one (ray, gaussian) pair; shared by forward (R2) and backward (recompute).
-struct LocalHit {
-    f3 lo, ld;      // object-space origin / un-normalised direction
-    f3 dhat;        // normalised object-space direction
-    float t;        // world distance of the max-response point
-    f3 u;           // unscaled local hit
-};
-EGR_DI void object_ray(const float4 *__restrict__ inst_w, uint32_t gid, f3 o, f3 d, f3 &lo, f3 &ld) {
-    float4 w0 = inst_w[4 * gid], w1 = inst_w[4 * gid + 1], w2 = inst_w[4 * gid + 2]; // 64-B records
-    lo = mk3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
-             w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
-    ld = mk3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z, w2.x * d.x + w2.y * d.y + w2.z * d.z);
+// The geometry of one (ray, gaussian) pair - object-space ray, closest-approach point, the two rejections that only need those
+// (shaders.cu:19-20, 36, 41-51) - in ONE function shared by the forward's candidate test and the backward's recomputation (bit-identical
+// t and u on both sides). EGR_UNFUSED_CANDIDATE = 1 compiles it without fma contraction, operation for operation what the CPU oracle
+// (-ffp-contract=off) and an unfused reading of the source evaluate; 0 lets the compiler fuse (nvcc's default for the reference too).
+#ifndef EGR_UNFUSED_CANDIDATE
+#define EGR_UNFUSED_CANDIDATE 0
+#endif
+#if EGR_UNFUSED_CANDIDATE
+#pragma clang fp contract(off)
+#endif
+EGR_DI void candidate_geometry(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &o, const f3 &d, f3 &lo, f3 &ld, f3 &dhat, float &t, f3 &u,
+                               bool &behind, bool &outside) {
+    lo.x = w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, lo.y = w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w, lo.z = w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w;
+    ld.x = w0.x * d.x + w0.y * d.y + w0.z * d.z, ld.y = w1.x * d.x + w1.y * d.y + w1.z * d.z, ld.z = w2.x * d.x + w2.y * d.y + w2.z * d.z;
+    const float norm = sqrtf(ld.x * ld.x + ld.y * ld.y + ld.z * ld.z); // :41
+    const float inv = 1.0f / norm;
+    dhat.x = ld.x * inv, dhat.y = ld.y * inv, dhat.z = ld.z * inv;      // :42
+    const float tl = (-lo.x) * dhat.x + (-lo.y) * dhat.y + (-lo.z) * dhat.z; // :43
+    t = tl / norm;                                                        // :44
+    u.x = lo.x + tl * dhat.x, u.y = lo.y + tl * dhat.y, u.z = lo.z + tl * dhat.z; // :45
+    behind = lo.x * ld.x + lo.y * ld.y + lo.z * ld.z > 0.0f;             // :36
+    outside = u.x * u.x + u.y * u.y + u.z * u.z > 1.0f;                   // :48-49
 }
-EGR_DI void closest_point(f3 lo, f3 ld, f3 &dhat, float &t, f3 &u) { // shaders.cu:41-45
-    float norm = length(ld);
-    dhat = ld * (1.0f / norm);
-    float tl = dot(-lo, dhat);
-    t = tl / norm;
-    u = lo + tl * dhat;
-}
+#if EGR_UNFUSED_CANDIDATE
+#pragma clang fp contract(fast)
+#endif
 // Wave-uniform node fetch: constant address space + uniform index => one s_load_dwordx8 through the scalar cache
 // (the tree is read-only for the whole launch) instead of a 64-lane vector load.
 typedef float egr_v8f __attribute__((ext_vector_type(8)));
