@@ -237,9 +237,9 @@ int egr_get_counters_ex(egr_context *c, void *out_raw, size_t out_bytes, void *s
                         k ? "bounce" : "primary", (unsigned long long)u64(CW_DBG2 + 16 + 10 * k), (unsigned long long)u64(CW_DBG2 + 18 + 10 * k),
                         (unsigned long long)u64(CW_DBG2 + 20 + 10 * k), (unsigned long long)u64(CW_DBG2 + 22 + 10 * k), (unsigned long long)u64(CW_DBG2 + 24 + 10 * k));
             for (int k = 0; k < 2; k++)
-                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | group walk: phase A %llu phase B %llu\n", k ? "bounce" : "primary",
-                        (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2), (unsigned long long)u64(CW_DBG2 + 8 + 4 * k),
-                        (unsigned long long)u64(CW_DBG2 + 8 + 4 * k + 2));
+                fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | of the traversal: leaf evaluation (frustum walk) %llu (slot +8: %llu)\n", k ? "bounce" : "primary",
+                        (unsigned long long)u64(CW_DBG2 + 4 * k), (unsigned long long)u64(CW_DBG2 + 4 * k + 2), (unsigned long long)u64(CW_DBG2 + 8 + 4 * k + 2),
+                        (unsigned long long)u64(CW_DBG2 + 8 + 4 * k));
         }
     });
     if (rc == 0) memcpy(out_raw, &full, out_bytes < sizeof(full) ? out_bytes : sizeof(full));

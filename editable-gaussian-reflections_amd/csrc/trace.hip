@@ -45,6 +45,9 @@
 #ifndef EGR_PAIR_PRIMARY
 #define EGR_PAIR_PRIMARY 0 // 1: primary rays walk pairwise too (0: one packet per tile)
 #endif
+#ifndef EGR_FRUSTUM_WALK
+#define EGR_FRUSTUM_WALK 1 // primary tiles: 1 = frustum walk (one interval test per child slot for the whole tile), 0 = the packet walk of rounds 1-3 (A/B only)
+#endif
 #ifndef EGR_PSTK
 #define EGR_PSTK 512 // pair-stack entries kept in LDS
 #endif
@@ -342,6 +345,7 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
 #define EGR_PRIMARY_TABLE 1 // 0 (measured: 4.8 instead of 3.3 ms): primary hits skip the LDS table and leave as records like bounce hits
 #endif
 #define EGR_GT_COMPS 22
+#define EGR_GT_STRIDE 23 // floats per table slot ([slot][component], odd stride: lanes on different slots fall on different LDS banks)
 #define EGR_GT_EMPTY 0xFFFFFFFFu
 // component order of the LDS table, of a wide-add record (first 15) and of a gradient row (DeviceView::grad_rows)
 enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_WEIGHT = 14, GC_NORMAL = 15, GC_F0 = 18, GC_ROUGH = 21 };
@@ -387,15 +391,15 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
         float lo[15], hi[15];
 #pragma unroll
         for (int c = 0; c < 15; c++) {
-            lo[c] = valid ? gt_vals[c * EGR_GT_SLOTS + s] : 0.0f;
-            if (valid) gt_vals[c * EGR_GT_SLOTS + s] = 0.0f; // (an unused slot holds zeros already)
+            lo[c] = valid ? gt_vals[s * EGR_GT_STRIDE + c] : 0.0f;
+            if (valid) gt_vals[s * EGR_GT_STRIDE + c] = 0.0f; // (an unused slot holds zeros already)
         }
 #pragma unroll
         for (int c = 0; c < 15; c++) {
             hi[c] = 0.0f;
             if (15 + c < EGR_GT_COMPS) {
-                hi[c] = valid ? gt_vals[(15 + c) * EGR_GT_SLOTS + s] : 0.0f;
-                if (valid) gt_vals[(15 + c) * EGR_GT_SLOTS + s] = 0.0f;
+                hi[c] = valid ? gt_vals[s * EGR_GT_STRIDE + 15 + c] : 0.0f;
+                if (valid) gt_vals[s * EGR_GT_STRIDE + 15 + c] = 0.0f;
             }
         }
         if (__ballot(valid) == 0ull) continue;
@@ -422,14 +426,15 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
 __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(EGR_BWD_WAVES, EGR_BWD_WAVES))) k_backward_chain(DeviceView v) {
     const int lane = threadIdx.x;
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
-    __shared__ float gt_vals[EGR_GT_COMPS * EGR_GT_SLOTS];
+    __shared__ float gt_vals[EGR_GT_STRIDE * EGR_GT_SLOTS];
+    __shared__ uint32_t gt_claim[EGR_GT_SLOTS]; // which lane adds to a slot in this round (backward_task.inc)
     __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (wide_add_wave)
 #if EGR_BWD_COMPACT
     __shared__ uint2 bitems[4 * EGR_WAVE];  // bounce steps: (ray | row << 6, dL/dalpha) of the hits of a chunk of four rows
     __shared__ float bdl[3 * EGR_WAVE];     // bounce steps: the rays' radiance gradient
 #endif
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
-    for (int s = lane; s < EGR_GT_COMPS * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
+    for (int s = lane; s < EGR_GT_STRIDE * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
     __syncthreads();
     const float exp_power = *v.cfg.exp_power;
     const float eps_scale_grad = *v.cfg.eps_scale_grad;

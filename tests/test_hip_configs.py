@@ -151,8 +151,8 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
       * every step's image >= 50 dB on the pixels of the clean tiles (below), >= 35 dB on all traced pixels (one bounce ray that
         meets another hit moves a 12k-pixel crop's step-2 depth to 39 dB);
       * all nine gradient tensors < 1e-3 of the oracle's max-abs on the CLEAN tiles - those where every pixel composites the
-        oracle's hit counts on every step (HIP: egr_debug_get_step_hits) and no two consecutive hits of the oracle lie within 4 ulps
-        of each other (their order decides their weights): 40 of 48 on the dense-init cloud, 8 of 48 on the
+        oracle's hit counts on every step (HIP: egr_debug_get_step_hits), minus at most three whose error is explained by two
+        consecutive hits of the oracle within 4 ulps of each other (their order decides their weights): 40 of 48 on the dense-init cloud, 8 of 48 on the
         trained-like cloud with its three full steps per pixel, nearly all with num_bounces = 0 (the third case);
       * on ALL tiles: < 2e-2, and fewer pixels differ in a hit count between HIP and the fp32 oracle than between the fp32 and
         the fp64 oracle (the HIP path is closer to the checker than the checker's arithmetic is to exact).
@@ -249,22 +249,31 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
 
     err_all = errors(ref, CROP_TILES)
     floor = {k: float(np.abs(ref[k] - ref64[k]).max() / np.abs(ref[k]).max()) for k in GRAD_KEYS}
-    # (two composited hits within 4 ulps of each other in the oracle: their ORDER, hence their two weights, hangs on the last bits of t)
-    differing = (np.any(hits_h != ref["num_composited_per_step"], axis=0) | (ref["num_depth_ties"] > 0)) & mask
+    differing = np.any(hits_h != ref["num_composited_per_step"], axis=0) & mask
     differing_oracles = np.any(ref["num_composited_per_step"] != ref64["num_composited_per_step"], axis=0) & mask
     ys, xs = np.nonzero(differing)
     listed = sorted({(int(x) // 16, int(y) // 16) for x, y in zip(xs, ys)})
     clean = [t for t in CROP_TILES if t not in listed]
+    # among those, tile by tile: a tile above the bar must hold a pixel where two consecutive composited hits of the oracle lie within
+    # 4 ulps of each other (their ORDER, hence their two weights, hangs on the last bits of t; exact ties: on the list order, which is
+    # unspecified upstream) - such tiles are listed too, and there may be few of them
+    tie_tiles = []
+    for t in list(clean):
+        ref_t, _ = oracle_on(o, [t])
+        if max(errors(ref_t, [t]).values()) >= 1e-3:
+            assert (ref["num_depth_ties"] > 0)[tile_mask([t])].any(), ("a tile with the oracle's hit counts, no near-tie, and a gradient off by more than 1e-3", t, errors(ref_t, [t]))
+            tie_tiles.append(t)
+            clean.remove(t)
     ref_clean, _ = oracle_on(o, clean)
     err_clean = errors(ref_clean, clean)
     levels_clean = image_levels(tile_mask(clean))
     fmt = lambda d: {k: f"{v:.1e}" for k, v in d.items()}
     report(f"config_c_crop_{variant}_bounces{bounces}", tiles=len(CROP_TILES), pixels=int(mask.sum()), composited=ref["num_composited_per_step"].sum(axis=(1, 2)).tolist(),
            psnr_min_all_tiles=min(levels.values()), psnr_min_clean_tiles=min(levels_clean.values()), psnr_clean_tiles=levels_clean, pixels_with_other_hit_counts=int(differing.sum()),
-           pixels_where_fp32_and_fp64_oracle_differ_in_hit_counts=int(differing_oracles.sum()), clean_tiles=len(clean),
+           pixels_where_fp32_and_fp64_oracle_differ_in_hit_counts=int(differing_oracles.sum()), clean_tiles=len(clean), tiles_listed_for_a_near_tie=tie_tiles,
            grad_err_clean_tiles=fmt(err_clean), grad_err_all_tiles=fmt(err_all), fp32_oracle_vs_fp64_oracle_all_tiles=fmt(floor))
     assert min(levels_clean.values()) >= 50.0 and min(levels.values()) >= 35.0, (levels_clean, levels)
-    assert len(clean) >= (40 if bounces == 0 else 6), (len(clean), len(CROP_TILES))
+    assert len(clean) >= (40 if bounces == 0 else 6) and len(tie_tiles) <= 3, (len(clean), tie_tiles, len(CROP_TILES))
     assert max(err_clean.values()) < 1e-3, err_clean
     assert max(err_all.values()) < 2e-2, err_all
     assert int(differing.sum()) <= int(differing_oracles.sum()), (int(differing.sum()), int(differing_oracles.sum()))
