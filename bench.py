@@ -235,7 +235,7 @@ def main():
             cc = m.get_counters()
             # Hc of SURVEY 8d = gaussians whose CUBE the segment overlaps (what the reference's intersection program is invoked for),
             # measured on the GPU by ONE exact-statistics launch of the same frame (cube boxes, egr_set_exact_stats); the default
-            # tree bounds ellipsoids and evaluates a subset (`evaluated_per_ray`). Every rank does this (same call sequence).
+            # tree bounds ellipsoids; a default launch counts the candidates inside their ellipsoid (`inside_ellipsoid_per_ray`). Every rank does this (same call sequence).
             m.set_exact_stats(True)
             m.update_bvh()
             m.get_metadata().total_num_calls.sub_(1)  # the same jitter / bounce random stream as the last profiled launch
@@ -252,7 +252,6 @@ def main():
             pixels_rank = rays[0]
             fk = "forward_nograd" if a.forward_only else "forward"
             fwd_ref = sum(algorithmic_bytes(fk, s, rays[s], cand[s], comp[s], pixels_rank) for s in range(3))
-            fwd_eval = sum(algorithmic_bytes(fk, s, rays[s], cand_eval[s], comp[s], pixels_rank) for s in range(3))
             cands = {"forward_chain": fwd_ref}
             if not a.forward_only:
                 cands["backward_chain"] = sum(algorithmic_bytes("backward", s, rays[s], cand[s], comp[s], pixels_rank) for s in range(3))
@@ -288,10 +287,9 @@ def main():
                 return r
 
             roof = roof_of(dom)
-            roof.update({"evaluated_frac": round((fwd_eval if dom == "forward_chain" else cands[dom]) / (kern[dom] * 1e-3) / 1e9 / 8000.0, 5),
-                         "rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
+            roof.update({"rays_per_step": [int(x) for x in rays], "Hc_per_ray": [round(cand[s] / max(rays[s], 1), 2) for s in range(3)],
                          "Hc_source": "one exact-statistics launch of the same frame on the GPU (cube boxes; reference-defined count)",
-                         "evaluated_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
+                         "inside_ellipsoid_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
                          "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
                          "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
                          "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2),

@@ -45,9 +45,6 @@
 #ifndef EGR_PAIR_PRIMARY
 #define EGR_PAIR_PRIMARY 0 // 1: primary rays walk pairwise too (0: one packet per tile)
 #endif
-#ifndef EGR_FRUSTUM_WALK
-#define EGR_FRUSTUM_WALK 1 // primary tiles: 1 = frustum walk (one interval test per child slot for the whole tile), 0 = the packet walk of rounds 1-3 (A/B only)
-#endif
 #ifndef EGR_PSTK
 #define EGR_PSTK 512 // pair-stack entries kept in LDS
 #endif
@@ -338,7 +335,7 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
 // so per-hit contributions are first summed in a per-wave LDS hash table (ds_add_f32, open addressing on the
 // record index) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
 #ifndef EGR_GT_SLOTS
-#define EGR_GT_SLOTS 64 // slots of the primary step's LDS table (any count >= 64; multiply-shift hash). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
+#define EGR_GT_SLOTS 94 // (round 4: 94 - what fits twelve waves per CU since the bounce queues share the table's memory; it was 64) slots of the primary step's LDS table (any count >= 64; multiply-shift hash). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
                         // per CU) and a hit that finds no slot leaves as wide adds anyway (trained 3.46 -> 3.25 ms, dense-init 7.7 -> 4.9 ms)
 #endif
 #ifndef EGR_PRIMARY_TABLE
@@ -426,12 +423,16 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
 __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(EGR_BWD_WAVES, EGR_BWD_WAVES))) k_backward_chain(DeviceView v) {
     const int lane = threadIdx.x;
     __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
-    __shared__ float gt_vals[EGR_GT_STRIDE * EGR_GT_SLOTS];
+    __shared__ __attribute__((aligned(16))) float gt_vals[EGR_GT_STRIDE * EGR_GT_SLOTS];
     __shared__ uint32_t gt_claim[EGR_GT_SLOTS]; // which lane adds to a slot in this round (backward_task.inc)
     __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (wide_add_wave)
 #if EGR_BWD_COMPACT
-    __shared__ uint2 bitems[4 * EGR_WAVE];  // bounce steps: (ray | row << 6, dL/dalpha) of the hits of a chunk of four rows
-    __shared__ float bdl[3 * EGR_WAVE];     // bounce steps: the rays' radiance gradient
+    // the two queues of the bounce steps live in the table's memory: the table is empty (flushed, all zero) while a tile's bounce steps run -
+    // they come before its primary step - and the words they dirtied are cleared again before that step (backward_task.inc). 2.75 KB less
+    // LDS per wave: 94 table slots instead of 64 at the same twelve waves per CU.
+    static_assert(EGR_GT_STRIDE * EGR_GT_SLOTS >= 11 * EGR_WAVE, "the bounce queues must fit into the table");
+    uint2 *bitems = reinterpret_cast<uint2 *>(gt_vals);  // [4 x 64] bounce steps: (ray | row << 6, dL/dalpha) of the hits of a chunk of four rows
+    float *bdl = gt_vals + 8 * EGR_WAVE;                 // [3 x 64] bounce steps: the rays' radiance gradient
 #endif
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < EGR_GT_STRIDE * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
@@ -445,12 +446,20 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q);
         if (tq == 0xFFFFFFFFu) break;
+        bool table_dirty = false; // (wave-uniform) a bounce step used the table's memory for its queues
         for (int step = num_bounces; step >= 1; step--) {
             constexpr bool PRIMARY = false;
             do {
 #include "backward_task.inc"
             } while (false);
         }
+#if EGR_BWD_COMPACT
+        if (table_dirty) {
+            __syncthreads();
+            for (int s = lane; s < 11 * EGR_WAVE; s += EGR_WAVE) gt_vals[s] = 0.0f;
+            __syncthreads();
+        }
+#endif
         {
             constexpr bool PRIMARY = true;
             const int step = 0;
@@ -648,6 +657,11 @@ void egr_trace_alloc(egr_context *c) {
     int per_cu = 0; // the forward chain is built for four waves per SIMD (faster with more waves in flight even with spills)
     EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_forward_chain<true, false>, EGR_WAVE, 0));
     per_cu = std::max(1, std::min(32, per_cu));
+    if (getenv("EGR_DEBUG_OCCUPANCY")) {
+        int bwd = 0;
+        EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, k_backward_chain, EGR_WAVE, 0));
+        fprintf(stderr, "[egr] resident waves per CU: forward chain %d, backward chain %d\n", per_cu, bwd);
+    }
     if (const char *e = getenv("EGR_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // tuning knob
     uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
     c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));

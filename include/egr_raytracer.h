@@ -92,14 +92,14 @@ typedef struct egr_metadata {
 /* core/stats.h:3-6 */
 typedef struct egr_stats {
     int32_t *num_accumulated_per_pixel; /* [H,W] composited hits of the LAST executed step (forward_pass.cu:140) */
-    int32_t *num_traversed_per_pixel;   /* [H,W] intersection-program invocations, all steps (forward_pass.cu:46); evaluated
-                                         * records unless egr_set_exact_stats is on (see there) */
+    int32_t *num_traversed_per_pixel;   /* [H,W] intersection-program invocations, all steps (forward_pass.cu:46) with egr_set_exact_stats;
+                                         * by default the subset of them whose response point lies inside the gaussian's ellipsoid (see there) */
 } egr_stats;
 
 /* Whole-launch work counters (not in the reference; used for the roofline's algorithmic bytes). */
 typedef struct egr_counters {
     uint64_t rays[EGR_NUM_STEPS];        /* rays traced per bounce step (a ray = one pixel x step)            */
-    uint64_t candidates[EGR_NUM_STEPS];  /* candidates per step: evaluated records, or Hc = cube overlaps with exact stats */
+    uint64_t candidates[EGR_NUM_STEPS];  /* candidates per step: those inside their ellipsoid (default), or Hc = cube overlaps with exact stats */
     uint64_t composited[EGR_NUM_STEPS];  /* composited hits per step (Kc)                                     */
     uint64_t lifetime_rays;              /* rays of ALL launches since egr_create / egr_reset_lifetime_counters */
     uint32_t lifetime_launches;
@@ -171,10 +171,12 @@ int egr_set_partition(egr_context *ctx, int rank, int world_size);
  * in between (one write pass over [22N] instead of a read-modify-write, and no memset per iteration). */
 int egr_set_grad_overwrite(egr_context *ctx, int enable);
 
-/* Exact statistics (not in the reference). By default the tree bounds each Gaussian's ELLIPSOID and the walk evaluates only the
- * instances whose response point can be accepted, so stats.num_traversed_per_pixel and egr_counters.candidates count the records
- * the walk EVALUATED (ellipsoid-box overlaps whose response point lies on the walked segment) - not the reference's
- * intersection-program invocations (cube overlaps, shaders.cu:33); every other output is unaffected.
+/* Exact statistics (not in the reference). By default the tree bounds each Gaussian's ELLIPSOID and the walk only has to find the
+ * instances whose response point can be accepted, so stats.num_traversed_per_pixel and egr_counters.candidates count the candidates
+ * whose response point lies INSIDE the ellipsoid (|u|^2 <= 1, shaders.cu:48) on the ray's segment - accepted ones plus the back-face /
+ * behind-the-origin rejections among them: a property of ray and gaussian, whatever the walk, and pixel by pixel a SUBSET of the reference's
+ * intersection-program invocations (every instance whose cube the segment overlaps, shaders.cu:33; about half of them on surfel
+ * clouds); every other output is unaffected.
  * With enable != 0 the next egr_update_bvh / egr_rebuild_bvh bounds the instance CUBES (what OptiX's TLAS holds) and every launch
  * counts exactly the instances whose unit cube the ray segment overlaps: the reference's number, at a slower walk. egr_raytrace
  * fails if the flag changed since the last refit. Used by tests and by bench.py to measure Hc. */

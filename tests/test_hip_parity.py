@@ -161,11 +161,13 @@ def test_forward_strict_parity_primary(ren, orc, syn, variant):
     assert np.abs(out["output_transmittance"] - ref["output_transmittance"]).max() < 2e-6
     report("strict_primary_" + variant, acc_mismatch=n_acc, acc_first=bad_acc, swapped_and_psnr=worst)
     assert n_acc <= 1, bad_acc  # measured: 0 on both variants
-    # default launches count the records the walk EVALUATED (ellipsoid boxes; include/egr_raytracer.h: egr_set_exact_stats), not the
-    # reference's intersection invocations; that count is compared in test_exact_stats_mode_counts_reference_invocations
+    # default launches count the candidates whose response point lies INSIDE the gaussian's ellipsoid on the ray's segment (a property of
+    # ray and gaussian, whatever the walk; include/egr_raytracer.h: egr_set_exact_stats) - a subset of the reference's intersection
+    # invocations (cube overlaps), pixel by pixel; that count itself is compared in test_exact_stats_mode_counts_reference_invocations
     ratio = float(ht.sum()) / float(ref["num_traversed"].sum())
-    report("default_statistic_" + variant, evaluated_over_reference_invocations=round(ratio, 3))
-    assert 0.75 < ratio < 1.35, ratio  # (bench scenes: 0.90 ... 1.07; a regression guard, not a parity claim)
+    report("default_statistic_" + variant, inside_ellipsoid_over_reference_invocations=round(ratio, 3))
+    assert 0.3 < ratio <= 1.0 and (ht > ref["num_traversed"]).sum() <= 2, (ratio, int((ht > ref["num_traversed"]).sum()))
+    assert (ht >= ha).all()  # every composited hit is one of them
     seeds = rt.cuda_module.get_metadata().random_seeds.cpu().numpy().astype(np.uint32).reshape(H, W)
     assert np.array_equal(seeds, ref["random_seeds"].reshape(H, W))
     c = rt.cuda_module.get_counters()
@@ -266,7 +268,7 @@ def test_golden_fixture(ren, orc, syn):
         assert psnr(out[k], z["ref_" + k]) > 50.0, k
     st = rt.cuda_module.get_stats()
     ht = st.num_traversed_per_pixel.cpu().numpy()
-    assert 0.75 * z["ref_num_traversed"].sum() < ht.sum() < 1.35 * z["ref_num_traversed"].sum()  # evaluated records (default mode)
+    assert 0.3 * z["ref_num_traversed"].sum() < ht.sum() <= z["ref_num_traversed"].sum()  # candidates inside their ellipsoid (default mode): a subset of the reference's invocations
     assert (st.num_accumulated_per_pixel.cpu().numpy() != z["ref_num_accumulated"]).mean() < 5e-3
     run_grad(ren, rt, cam_obj(ren, cam, tg))
     gr = hip_grads(rt)
