@@ -19,3 +19,19 @@ for call in [int(x) for x in os.environ.get("CALLS", "10,11").split(",")]:
     ok = (d >= 0).all(1)
     o = np.argsort(-np.where(ok, tot, 0))[:6]
     print(f"call {call}: heaviest chains (us: total | step 0, 1, 2):", [(round(float(tot[i]), 1), [round(float(x), 1) for x in d[i]], "tile", int(i % (W // 8)), int(i // (W // 8))) for i in o], "mean", round(float(tot[ok].mean()), 1), flush=True)
+    # how full the wave slots are over the kernel, and what other tile orders of the SAME chain durations would give (list scheduling)
+    import heapq
+    start, end = t[ok, 0], t[ok, 3]
+    base = start.min(); s, e = start - base, end - base; dur = e - s
+    slots = int(os.environ.get("SLOTS", 4096))
+    def sim(order):
+        h = [0.0] * slots; heapq.heapify(h); fin = 0.0
+        for i in order:
+            x = heapq.heappop(h); heapq.heappush(h, x + dur[i]); fin = max(fin, x + dur[i])
+        return fin
+    # longest first inside each of the 8 XCD chunks only (compact image blocks stay together): chunks = 4 x 2 blocks of the image
+    tx, ty = np.arange(len(ok))[ok] % (W // 8), np.arange(len(ok))[ok] // (W // 8)
+    blk = np.minimum(3, tx * 4 // (W // 8)) + 4 * np.minimum(1, ty * 2 // (H // 8))
+    per_chunk = [np.flatnonzero(blk == b)[np.argsort(-dur[blk == b])] for b in range(8)]
+    inter = [int(x) for tup in zip(*[list(p) + [-1] * (max(map(len, per_chunk)) - len(p)) for p in per_chunk]) for x in tup if x >= 0]
+    print(f"   span {e.max():.0f} us | sum / {slots} slots {dur.sum() / slots:.0f} | list schedule: start order {sim(np.argsort(s)):.0f}, longest first {sim(np.argsort(-dur)):.0f}, longest first inside each XCD block {sim(inter):.0f} | last start {s.max():.0f}", flush=True)

@@ -18,9 +18,10 @@ if os.environ.get("CALL"):  # the launch with this call number (= jitter / bounc
     with torch.no_grad(): rt(camera)
 torch.cuda.synchronize()
 st = m.get_stats()
-t0 = st.num_traversed_per_pixel.view(H, W)[::8, ::8].cpu().numpy().astype(np.int64).ravel()
-t1 = st.num_accumulated_per_pixel.view(H, W)[::8, ::8].cpu().numpy().astype(np.int64).ravel()
-tm = st.num_traversed_per_pixel.view(H, W)[::8, 1::8].cpu().numpy().astype(np.int64).ravel()
+RY = 4 if int(os.environ.get("EGR_RAYS_PER_TASK", "64")) == 32 else 8  # task height in pixels (8x8 tasks, or 8x4 with EGR_RAYS_PER_TASK=32)
+t0 = st.num_traversed_per_pixel.view(H, W)[::RY, ::8].cpu().numpy().astype(np.int64).ravel()
+t1 = st.num_accumulated_per_pixel.view(H, W)[::RY, ::8].cpu().numpy().astype(np.int64).ravel()
+tm = st.num_traversed_per_pixel.view(H, W)[::RY, 1::8].cpu().numpy().astype(np.int64).ravel()
 own = t1 > t0
 t0, t1, tm = t0[own], t1[own], tm[own]
 walk, sel = (tm - t0) * 0.01, (t1 - tm) * 0.01
@@ -30,8 +31,8 @@ print("all tasks: walk share of the task time: mean", float(walk.sum() / (walk.s
 base = t0.min()
 s, e = (t0 - base) * 0.01, (t1 - base) * 0.01  # us
 dur = e - s
-slots = int(m.get_counters()[10]) if False else 3072
-print("tasks", len(s), "kernel span us", e.max(), "sum of task times / 3072 slots", dur.sum() / slots, "max task", dur.max(), "mean", dur.mean())
+slots = int(os.environ.get("SLOTS", 4096))  # resident waves of the forward chain (16 per CU x 256 CUs)
+print("tasks", len(s), "kernel span us", e.max(), f"sum of task times / {slots} slots", dur.sum() / slots, "max task", dur.max(), "mean", dur.mean())
 # occupancy over time
 for frac in (0.25, 0.5, 0.75, 0.9, 1.0):
     T = e.max() * frac
@@ -46,6 +47,16 @@ def simulate(order):
         t = heapq.heappop(h)
         heapq.heappush(h, t + dur[i]); end = max(end, t + dur[i])
     return end
+# what intra-tile parallelism could buy: every task split over k waves without loss (k x the tasks at 1/k of the time each), and the
+# same with only the walk / evaluation part split (selection + compositing stay on one wave per ray)
+for k in (2, 4):
+    def sim(durs):
+        h = [0.0] * slots; heapq.heapify(h); end = 0.0
+        for dd in sorted(durs, reverse=True):
+            t = heapq.heappop(h); heapq.heappush(h, t + dd); end = max(end, t + dd)
+        return end
+    both = sim(np.repeat(dur / k, k))
+    print(f"bound with every task split over {k} waves: {both:.1f} us (longest first); heaviest task / {k}: {dur.max() / k:.1f} us; walk split only, heaviest: {(walk / k + sel).max():.1f} us")
 print("list schedule, same durations: start order", simulate(np.argsort(s)), " longest first", simulate(np.argsort(-dur)), " shortest first", simulate(np.argsort(dur)))
 full = np.zeros(own.shape, np.float64); full[own] = dur  # per tile, raster order (0 = not this rank's)
 np.save(os.path.join(ROOT, "gpurun_out", f"task_dur_w{world}_step{os.environ['TT_STEP']}.npy"), full)
