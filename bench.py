@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
     p.add_argument("--emulate-rank", type=int, default=0, help="which rank's tiles --emulate-world traces")
     p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
+    p.add_argument("--team-help", type=int, default=-1, help="egr_set_team_help: waves without tiles help their team mates' walks (1 / 0); default: on for ranks of a partition (--gpus N > 1, --emulate-world), off for a whole image")
     p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
     a = p.parse_args()
     if a.config == "B":
@@ -142,6 +143,8 @@ def main():
         if a.emulate_world > 1:
             assert world == 1
             m.set_partition(a.emulate_rank, a.emulate_world)
+        team_help = a.team_help == 1 or (a.team_help < 0 and (world > 1 or a.emulate_world > 1))
+        m.set_team_help(team_help)
 
         def one_step():
             if a.forward_only:
@@ -319,7 +322,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {a.config}: synthetic dense-init room+spheres cloud, HEADLINE variant = {a.variant} ({label[a.variant]}; "
                                    f"the other variant is in `other_variant`), N={N}, {W}x{H}, {what}, num_bounces={a.bounces}, jitter on, reference default config",
-                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients"},
+                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients", "team_help": bool(a.team_help == 1 or (a.team_help < 0 and (world > 1 or a.emulate_world > 1)))},
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"], "kernel_ms": main_res["kernel_ms"],
             "value_primary_only": (main_res.get("primary_only") or {}).get("value"), "primary_only": main_res.get("primary_only"),
             "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None, "device_bytes": main_res.get("device_bytes"),

@@ -66,6 +66,7 @@ def lib(path=None):
         L.egr_set_grad_overwrite.argtypes = [P, C.c_int]
         L.egr_set_strands.argtypes = [P, C.c_int]
         L.egr_set_rays_per_task.argtypes = [P, C.c_int]
+        L.egr_set_team_help.argtypes = [P, C.c_int]
         L.egr_get_counters.argtypes = [P, C.POINTER(egr_counters), P]
         L.egr_get_counters_ex.argtypes = [P, P, C.c_size_t, P]
         L.egr_last_error.argtypes = [P]

@@ -52,7 +52,7 @@ template <class F> int guarded(egr_context *c, F &&f) {
 
 extern "C" {
 
-const char *egr_version(void) { return "egr-hip 0.4 (gfx950)"; } // 0.4: egr_counters grew (round 3), egr_get_counters_ex, egr_set_rays_per_task
+const char *egr_version(void) { return "egr-hip 0.5 (gfx950)"; } // 0.4: egr_counters grew (round 3), egr_get_counters_ex, egr_set_rays_per_task; 0.5: egr_set_team_help
 
 int egr_create(egr_context **out, int device, int width, int height, int64_t ppll_forward_size, int64_t ppll_backward_size) {
     if (!out || width <= 0 || height <= 0) return 1;
@@ -65,6 +65,7 @@ int egr_create(egr_context **out, int device, int width, int height, int64_t ppl
     c->device = device, c->width = width, c->height = height;
     c->fwd_capacity = ppll_forward_size > 0 ? ppll_forward_size : 1, c->bwd_capacity = ppll_backward_size > 0 ? ppll_backward_size : 1;
     if (const char *e = getenv("EGR_DENOISE")) c->denoise_mode = atoi(e);
+    if (const char *e = getenv("EGR_TEAM_HELP")) c->team_help = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("EGR_STRANDS")) c->strands = std::max(1, std::min(EGR_MAX_STRANDS, atoi(e)));
     int rc = guarded(c, [&] {
         egr_trace_alloc(c);
@@ -130,6 +131,12 @@ int egr_set_exact_stats(egr_context *c, int enable) {
 int egr_set_rays_per_task(egr_context *c, int rays_per_task) {
     if (!c || !(rays_per_task == 0 || rays_per_task == 16 || rays_per_task == 32 || rays_per_task == 64)) return 1;
     c->rays_per_task = rays_per_task;
+    return 0;
+}
+
+int egr_set_team_help(egr_context *c, int on) {
+    if (!c || !(on == 0 || on == 1)) return 1;
+    c->team_help = on;
     return 0;
 }
 
@@ -232,6 +239,7 @@ int egr_get_counters_ex(egr_context *c, void *out_raw, size_t out_bytes, void *s
             for (int k = 0; k < 3; k++)
                 fprintf(stderr, "[egr stats forward step %d] first wave exit -> last wave exit: %.3f ms\n", k,
                         (double)(u64(CW_DBG3 + 4 * k + 2) - u64(CW_DBG3 + 4 * k)) / 100e6 * 1e3);
+            fprintf(stderr, "[egr stats team] offers made %u, offers walked by helpers %u (their walk batches: %u), owner walk batches that left >= EGR_DONATE_MIN pairs on the stack %u\n", c->control_host[CW_DBG3 + 12], c->control_host[CW_DBG3 + 13], c->control_host[CW_DBG3 + 14], c->control_host[CW_DBG3 + 15]);
             for (int k = 0; k < 2; k++)
                 fprintf(stderr, "[egr stats backward %s] wave-cycles(s_memtime) per-hit math %llu, neighbour combine + LDS table %llu, wide adds %llu, table flush %llu; hit rows %llu\n",
                         k ? "bounce" : "primary", (unsigned long long)u64(CW_DBG2 + 16 + 10 * k), (unsigned long long)u64(CW_DBG2 + 18 + 10 * k),

@@ -99,6 +99,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t *queues;      // [strands][2 kernels][8 XCD heads] task queue heads; this view's strand starts at `queues`
     uint32_t num_strands;
     int grad_overwrite;    // k_grad_gather stores this launch's sums (per-launch buffer, egr_set_grad_overwrite) instead of adding them
+    int team_help;         // forward chain: waves without tiles (or waiting for their own helpers) walk pairs their team mates offer (trace.hip: teams)
     int cube_mode;         // exact-statistics launch (egr_set_exact_stats): the tree bounds instance CUBES, every overlap is counted
 };
 
@@ -182,12 +183,14 @@ struct egr_context {
     hipEvent_t ev_fork = nullptr, ev_join[EGR_MAX_STRANDS] = {};
     uint32_t *queues = nullptr;
     uint32_t cand_cap = 0, num_slots = 0;
+    int team_waves_per_cu = 0; // resident waves per CU of the forward chain's team build (whole teams)
     float4 *hit_arena = nullptr;
     uint32_t hit_blocks_cap = 0;
     uint32_t *task_last_block = nullptr;
     float *state = nullptr;
     uint32_t state_stride = 0;
     uint32_t num_tasks_total = 0; // 8x8 wave tiles in the whole image (a 16x16 macro tile = 4 of them = 256 rays of ray state)
+    int team_help = 0;            // egr_set_team_help / env EGR_TEAM_HELP: 1 = waves without tiles help their team mates' walks (forward outputs then depend on timing in their last bits)
     int rays_per_task = 0;        // 0: automatic (64; 32 for a rank of a partition with fewer than two 8x8 tiles per wave slot); env EGR_RAYS_PER_TASK
     uint32_t *task_macro = nullptr; // device table of the current partition's tile order: one of task_orders[].table
     struct TaskOrder {              // tile orders built so far (a partitioned trainer flips between (rank, world) for training launches and

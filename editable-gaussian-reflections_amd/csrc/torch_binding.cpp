@@ -406,6 +406,7 @@ struct Raytracer : torch::CustomClassHolder {
     // count (cube boxes, slower). Takes effect with the next update_bvh() / rebuild_bvh(); raytrace() refuses to run in between.
     void set_exact_stats(bool on) { check(egr_set_exact_stats(ctx, on ? 1 : 0), "set_exact_stats"); }
     void set_rays_per_task(int64_t n) { TORCH_CHECK(egr_set_rays_per_task(ctx, (int)n) == 0, "set_rays_per_task: 0 (automatic), 16, 32 or 64 expected"); }
+    void set_team_help(bool on) { TORCH_CHECK(egr_set_team_help(ctx, on ? 1 : 0) == 0, "set_team_help failed"); }
     void set_strands(int64_t n) { TORCH_CHECK(egr_set_strands(ctx, (int)n) == 0, "set_strands: 1..EGR_STRANDS (value at creation) expected"); }
     std::vector<int64_t> get_counters() { // synchronises
         egr_counters c{};
@@ -499,6 +500,7 @@ struct Raytracer : torch::CustomClassHolder {
             .def("use_grad_delta", &Raytracer::use_grad_delta)
             .def("set_exact_stats", &Raytracer::set_exact_stats)
             .def("set_strands", &Raytracer::set_strands)
+            .def("set_team_help", &Raytracer::set_team_help)
             .def("set_rays_per_task", &Raytracer::set_rays_per_task)
             .def("get_counters", &Raytracer::get_counters)
             .def("reset_lifetime_counters", &Raytracer::reset_lifetime_counters)

@@ -56,14 +56,14 @@ namespace {
 // used for speed only, any placement is correct), then steals from the others. Each XCD's private 4 MiB L2 then
 // holds one band's BVH nodes / Gaussian records instead of the whole frame's, and the single shared head no
 // longer serialises 6144 pullers (microarch guide, "dequeue": shard the head per XCD above 64 pullers).
-EGR_DI uint32_t wave_next_task(uint32_t *heads, uint32_t num_tasks, uint32_t &cur_q) {
+EGR_DI uint32_t wave_next_task(uint32_t *heads, uint32_t num_tasks, uint32_t &cur_q, int lane) {
     const uint32_t chunk = ((num_tasks + 7u) / 8u + 3u) & ~3u;
     for (uint32_t tries = 0; tries < 8u; tries++) {
         const uint32_t q = (cur_q + tries) & 7u;
         const uint32_t beg = q * chunk, end = min(beg + chunk, num_tasks);
         if (beg >= end) continue;
         uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(heads + q, 1u);
+        if (lane == 0) t = atomicAdd(heads + q, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (beg + t < end) {
             cur_q = q;
@@ -225,6 +225,370 @@ EGR_DI bool hits_unit_cube_exact(f3 lo, f3 ld, float tmin, float tmax) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward chain: teams, the candidate test and the pair walk
+// ---------------------------------------------------------------------------------------------------------
+// A workgroup of the forward chain is a TEAM of EGR_TEAM waves. Every wave still owns its tiles alone (its own queue pulls, stack,
+// leaf buffer, ray table, candidate scratch: waves never wait for each other while there are tiles), but the LDS is shared, and that
+// is what lets SEVERAL WAVES WORK ON ONE HEAVY TILE: a wave that finds the task queue empty stays as a HELPER, and a wave whose pair
+// stack is long while a team mate idles puts the upper half of it (up to EGR_BOX pairs) on offer. The helper walks those pairs on its
+// own stack and leaf buffer against the OWNER's ray table, and its accepted candidates take slots of the owner's lists through the
+// owner's LDS counters - exactly what the owner would have done with them, in another order (the list order of a ray is an
+// implementation matter). A rank of an 8-way partition has one or two tiles per wave slot and its launch used to last
+// as long as ONE wave needed for the heaviest tile's walk.
+#ifndef EGR_TEAM
+#define EGR_TEAM 16 // waves per workgroup of the forward chain's team build: the chain exists twice, as teams of this size for launches with
+                    // egr_set_team_help(1) and as single-wave workgroups for all others (a team's LDS stays allocated until its last wave
+                    // leaves, which costs a whole image 3 % of the chain when nobody helps; 16 = all the waves of a CU can help each other:
+                    // rank 0 of an emulated 8-way partition, forward chain 1.60-1.65 ms against 1.66-1.87 with 4 and 1.79 without help)
+#endif
+#ifndef EGR_BOX
+#define EGR_BOX 128 // (ray, node) pairs one offer holds
+#endif
+#ifndef EGR_DONATE_MIN
+#define EGR_DONATE_MIN 96 // an owner offers half of its stack from this height on
+#endif
+#define EGR_BOX_CLAIMED 0x80000000u
+#define EGR_EXT_LOCKED (EGR_EXT_NONE - 2u) // a wave of the team is fetching this ray's extension block right now
+
+// The waves of a team run independently, so the kernel has NO workgroup barrier. Within one wave LDS instructions execute in program
+// order (a lane reads what another lane of its wave stored by an earlier instruction): all a wave needs between phases that exchange
+// data through LDS is that the compiler keeps the order.
+EGR_DI void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// (volatile accesses keep their generic address space - the compiler would emit flat_load / flat_store for LDS words - so the cast names LDS)
+typedef __attribute__((address_space(3))) uint32_t egr_lds_u32;
+EGR_DI uint32_t lds_peek(const uint32_t *p) { return *(const volatile egr_lds_u32 *)p; }
+EGR_DI void lds_poke(uint32_t *p, uint32_t x) { *(volatile egr_lds_u32 *)p = x; }
+EGR_DI uint32_t uniform_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+struct FwdConst { // launch constants of a forward wave
+    float exp_power, transmittance_threshold, backfacing_max_dist, backfacing_thr, far_plane;
+    int num_bounces;
+    bool sentinels;
+    const float4 *__restrict__ app;
+    const uint4 *__restrict__ wnodes;
+};
+struct WalkShared { // one wave's LDS
+    uint32_t pstk[EGR_PSTK];  // (ray << 26 | wide node); entries beyond EGR_PSTK spill to the wave's global column
+    uint32_t lbuf[EGR_LBUF];  // (ray << 26 | record) awaiting evaluation; a walk batch adds <= 8 GPOP x 8 and only runs when that fits
+    float4 rayp[EGR_WAVE][3]; // per ray: (o.xyz, d.x) (d.yz, invq.xy) (invq.z, ncq.xyz)
+    uint32_t gcnt[EGR_WAVE], gtrav[EGR_WAVE]; // accepted / counted candidates per ray
+    uint32_t gext[EGR_WAVE];  // extension block of a ray's candidate list (EGR_EXT_NONE: none)
+    uint32_t wc[4 * EGR_NSTEPS]; // this wave's ray / candidate / composited / accepted counts per step
+};
+template <int TEAM> struct TeamShared {
+    uint32_t done;                 // waves of the team that found the task queue empty (they only help from then on)
+    uint32_t hungry;               // waves looking for an offer right now (out of tiles, or waiting for the helpers of their own walk)
+    uint32_t box_count[TEAM];  // the offer of wave w: pairs | rays' owner << 16 (0: none; EGR_BOX_CLAIMED set: being copied out)
+    uint32_t busy[TEAM];       // other waves that hold pairs of wave w's current walk (a wave announces itself here BEFORE it claims an offer)
+    uint32_t ctx[TEAM][5];     // the walk wave w's offers belong to: step | seg << 8, seg_lo, seg_hi, near plane, the wave whose rays these are
+    uint32_t box[TEAM][EGR_BOX];
+};
+#if defined(EGR_TRAVERSAL_STATS) || defined(EGR_TASK_TIMES)
+#define EGR_WALK_STATS 1
+#endif
+struct WalkStats { // diagnostic builds (EGR_TRAVERSAL_STATS, EGR_TASK_TIMES)
+    uint32_t visits = 0, leafhits = 0, inner = 0, outer = 0;
+    uint32_t offers = 0, tall = 0; // team: offers made, walk batches that left the stack at EGR_DONATE_MIN pairs or more
+};
+
+// R2 for one (ray, gaussian) pair given the gaussian's W rows and live (.., opacity, sigma) record (shaders.cu:9-75).
+// `prim` is the gaussian's SORTED POSITION (record index), not its id.
+// returns 0: not this segment's / not met by the reference, 1: counted and rejected, 2: accepted (t, alpha valid), 3: response point outside
+// the ellipsoid (rejected; counted only by the exact-statistics build). What a DEFAULT launch counts (num_traversed_per_pixel,
+// egr_counters.candidates) is a property of the ray and the gaussian alone, not of how the tree was walked: the candidates whose response
+// point lies INSIDE the gaussian's ellipsoid on the ray's segment - a subset of the reference's intersection-program invocations
+// (every instance whose CUBE the segment overlaps, shaders.cu:33), which the exact-statistics build counts (egr_set_exact_stats).
+// SEG0: the caller's copy of the loop only runs for segment 0 (the hot case: no runtime segment dispatch).
+template <bool CUBE, bool SEG0, class A2>
+EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plane, const f3 &o, const f3 &d, uint32_t prim, const float4 &w0, const float4 &w1,
+                          const float4 &w2, A2 a2src, float &t, float &alpha) {
+    const float far_plane = fc.far_plane;
+    f3 lo, ld, dhat, u;
+    bool behind, outside;
+    candidate_geometry(w0, w1, w2, o, d, lo, ld, dhat, t, u, behind, outside); // :19-20, :36, :41-51
+    if constexpr (CUBE) {
+        // exact-statistics build: the tree bounds the instance cubes, one walk over [tmin,tmax] meets every instance OptiX
+        // would invoke the intersection program for; the cube test is the oracle's (IEEE division)
+        if (!hits_unit_cube_exact(lo, ld, near_plane, far_plane)) return 0;
+    } else {
+        // each candidate is owned by exactly one of the three walked segments (forward_task.inc): counted / accepted once
+        if constexpr (SEG0) {
+            if (!(t >= near_plane && t <= far_plane)) return 0;
+        } else if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return 0;
+        // OptiX only invokes the intersection program when the instance's unit cube overlaps [tmin,tmax]. A response point
+        // inside the unit sphere AND on the segment (segment 0) is itself a point of cube and segment, so the cube test is
+        // implied for everything segment 0 ACCEPTS; the hits it rejects (behind, outside the sphere) are counted without asking
+        // whether the reference would have looked at them (default launches count evaluated records, egr_set_exact_stats counts
+        // the reference's invocations). Segments 1 / 2 hold the Q1 hits, accepted only if the cube overlaps [tmin,tmax].
+        if constexpr (!SEG0)
+            if (seg != 0 && !hits_unit_cube(lo, ld, near_plane, far_plane)) return 0;
+    }
+    if (outside) return CUBE ? 1 : 3;               // :48-51 (the exact-statistics build counts every invocation, shaders.cu:33)
+    if (behind) return 1;                           // :36
+    if (step != 0 && t < fc.backfacing_max_dist) {  // :54-61 (world normal . object dir)
+        const float4 n0 = fc.app[2 * prim], n1 = fc.app[2 * prim + 1]; // raw normal, record order (k_live)
+        f3 gn = mk3(n0.w, n1.x, n1.y);
+        if (length(gn) > fc.backfacing_thr && dot(gn, dhat) > 0.0f) return 1;
+    }
+    const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
+    f3 x = u * a2.w;                                          // :64
+    float gaussval = eval_gaussian_sq(dot(x, x), fc.exp_power); // :65
+    alpha = EGR_MAX_ALPHA * gaussval * a2.z;                   // kernel.cu:14-16
+    return 2;
+}
+
+// ---- pair walk. Work items are PAIRS, not rays: a wave-wide LIFO of (ray, node) pairs and a buffer of (ray, leaf) pairs,
+// both in LDS. A walk iteration pops up to 8 x EGR_GPOP pairs; lane m of group g tests child slot m of the g-th popped node
+// (one 16-B load per lane = the node's 128-B line per group), hits are compacted with wave-wide ballots: inner children
+// back onto the stack, leaves into the leaf buffer. Whenever 64 leaf pairs wait, ONE LANE PER PAIR evaluates them (every
+// lane busy, no per-ray open / close, no leaf queue in global memory). Accepted candidates take a slot of their ray's list
+// through an LDS counter; the total transmittance is multiplied up from the finished list (its order, like the
+// reference's insertion order, is an implementation matter: deterministic for a wave that walks alone).
+// The loop exists once per decode of the child boxes (SENT: out-of-frame sentinels or not, wave-uniform for the whole launch) and once more
+// for segment 0 without sentinels (SEG0; nearly every walk of a bounce step) - the choice is made once per walk instead of once per slot batch.
+// `mine`: stack and leaf buffer of the executing wave; `rays`: ray table, per-ray counters and (through scratch0) candidate lists of the
+// wave that OWNS the tile - the same wave unless HELPER. The owner enters with `top` pairs on mine.pstk, a helper with the pairs it took.
+template <bool SENT, bool SEG0, bool CUBE, int TEAM>
+EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine, WalkShared &rays, TeamShared<TEAM> &team, const int self, const size_t scratch0,
+                      uint32_t *__restrict__ gstk, const int step, const int seg, const float seg_lo, const float seg_hi, const float near_plane, uint32_t top,
+                      bool &g_over, WalkStats &st) {
+    const int lane = threadIdx.x & (EGR_WAVE - 1);
+    const uint32_t m = (uint32_t)lane & 7u, grp = (uint32_t)lane >> 3;
+    constexpr uint32_t GSTK_CAP = (uint32_t)EGR_GSTK * EGR_WAVE;
+    const uint4 *__restrict__ wnodes = fc.wnodes;
+    uint32_t nl = 0u; // wave-uniform height of the leaf buffer (top: of the pair stack)
+    uint32_t idle_seen = 0u;
+    for (;;) {
+        // One iteration = (up to) one evaluation batch AND one walk batch: the record fetches of the batch of 64 leaf pairs and
+        // the node fetches of the popped pairs are issued together, then both are worked off - a tile's critical path is its
+        // chain of dependent fetches (every batch needs what the previous one found), so two kinds of work per round trip
+        // instead of one shorten it (the walk refills the leaf buffer with ~40 pairs per iteration).
+        const bool do_eval = nl >= (uint32_t)EGR_WAVE || (top == 0u && nl > 0u); // wave-uniform
+        if (!do_eval && top == 0u) {
+            if constexpr (TEAM > 1) {
+                // an offer of this wave that nobody took comes back. (One that is being copied out right now is the taker's: it announced
+                // itself in busy[rays' owner] before it claimed the offer, and that owner waits for it - forward_task.inc.)
+                uint32_t r = 0u;
+                if (lane == 0) {
+                    const uint32_t c = lds_peek(&team.box_count[self]);
+                    if (c != 0u && !(c & EGR_BOX_CLAIMED) && atomicCAS(&team.box_count[self], c, c | EGR_BOX_CLAIMED) == c) r = c;
+                }
+                r = uniform_u32(r);
+                if (r != 0u) {
+                    r &= 0xFFFFu;
+                    for (uint32_t i = (uint32_t)lane; i < r; i += EGR_WAVE) mine.pstk[i] = team.box[self][i];
+                    top = r;
+                    wave_sync();
+                    if (lane == 0) lds_poke(&team.box_count[self], 0u);
+                    continue;
+                }
+            }
+            break;
+        }
+        // ---------------- issue: evaluation batch (64 (ray, leaf) pairs, one lane each)
+        bool have = false;
+        uint32_t er = 0u, pidx = 0u;
+        float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0; // the whole 64-B record: rows of W + the live quarter (same line)
+        if (do_eval) {
+            const uint32_t take = min(nl, (uint32_t)EGR_WAVE);
+            nl -= take;
+            have = (uint32_t)lane < take;
+            const uint32_t pr = mine.lbuf[nl + min((uint32_t)lane, take - 1u)];
+            er = pr >> 26, pidx = pr & 0x03FFFFFFu;
+            if (have) w0 = v.inst_w[4 * pidx], w1 = v.inst_w[4 * pidx + 1], w2 = v.inst_w[4 * pidx + 2], w3 = v.inst_w[4 * pidx + 3];
+        }
+        // ---------------- issue: walk batch (pop up to 8 x EGR_GPOP (ray, node) pairs)
+        // (a walk batch only runs when the leaf pairs it can add fit the buffer: otherwise this iteration only evaluates)
+        const uint32_t npop = ((EGR_PIPELINE || !do_eval) && nl + (uint32_t)EGR_WALK_MAX_LEAVES <= (uint32_t)EGR_LBUF) ? min(top, 8u * (uint32_t)EGR_GPOP) : 0u;
+        uint32_t pw[EGR_GPOP];
+        uint4 sl_[EGR_GPOP];
+        if constexpr (TEAM > 1) idle_seen = lds_peek(&team.hungry); // (read with the stack: one LDS round trip)
+        if (npop != 0u) {
+#pragma unroll
+            for (int u = 0; u < EGR_GPOP; u++) pw[u] = mine.pstk[min(top - 1u - min(grp + 8u * (uint32_t)u, top - 1u), (uint32_t)EGR_PSTK - 1u)];
+            if (top > (uint32_t)EGR_PSTK) { // some popped pairs live in the global spill column (rare; volatile keeps it a global load)
+#pragma unroll
+                for (int u = 0; u < EGR_GPOP; u++) {
+                    const uint32_t e = top - 1u - min(grp + 8u * (uint32_t)u, top - 1u);
+                    if (grp + 8u * (uint32_t)u < npop && e >= (uint32_t)EGR_PSTK) pw[u] = *reinterpret_cast<const volatile uint32_t *>(gstk + (e - EGR_PSTK));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EGR_GPOP; u++) {
+                // (a group beyond the popped pairs re-reads the bottom pair's node - a valid entry, the index above is clamped - and is
+                // turned into an empty slot: no exec-mask detour around the load)
+                sl_[u] = wnodes[(size_t)(pw[u] & 0x03FFFFFFu) * EGR_WIDTH + m];
+                if (!(grp + 8u * (uint32_t)u < npop)) sl_[u].w = EGR_EMPTY_SLOT;
+            }
+            top -= npop;
+#ifdef EGR_WALK_STATS
+            st.visits += (m == 0u) ? min(npop > grp ? (npop - grp + 7u) / 8u : 0u, (uint32_t)EGR_GPOP) : 0u;
+            st.inner += (lane == 0);
+#endif
+        }
+        wave_sync(); // the reads of both buffers above come before the pushes below
+        // ---------------- work off: evaluation batch
+        if (do_eval) {
+            int res = 0;
+            float t = 0.0f, alpha = 0.0f;
+            if (have) {
+                const float4 q0 = rays.rayp[er][0], q1 = rays.rayp[er][1];
+                res = test_candidate<CUBE, SEG0>(fc, step, seg, near_plane, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), pidx, w0, w1, w2, w3, t, alpha);
+            }
+#ifdef EGR_WALK_STATS
+            st.leafhits += have ? 1u : 0u;
+            st.outer += (lane == 0);
+#endif
+            if (res == 1 || res == 2) atomicAdd(&rays.gtrav[er], 1u);
+            uint32_t at = 0u;
+            if (res == 2) at = atomicAdd(&rays.gcnt[er], 1u);
+            const bool in_ext = res == 2 && at >= v.cand_cap;
+            if (res == 2 && !in_ext) {
+                const size_t slot = (scratch0 + er) * v.cand_cap + at;
+                v.cand_keys[slot] = t, v.cand_vals[slot] = make_float2(alpha, u2f(pidx));
+            }
+            if (__ballot(in_ext) != 0ull) { // rare: some list outgrew its run - it continues in ONE extension block per ray
+                for (;;) { // rays that need a block and have none, one after the other (wave-uniform loop)
+                    const unsigned long long pend = __ballot(in_ext && lds_peek(&rays.gext[er]) == EGR_EXT_NONE);
+                    if (pend == 0ull) break;
+                    const int src = __ffsll((long long)pend) - 1;
+                    if (lane == src && atomicCAS(&rays.gext[er], EGR_EXT_NONE, EGR_EXT_LOCKED) == EGR_EXT_NONE) { // (a team mate working on the same ray may be faster)
+                        const uint32_t e = atomicAdd(v.control + CW_EXT_BUMP, 1u);
+                        lds_poke(&rays.gext[er], e < v.ext_blocks_cap ? e : EGR_EXT_NONE - 1u); // EGR_EXT_NONE - 1 = none left
+                    }
+                    wave_sync();
+                }
+                if (in_ext) {
+                    uint32_t e = lds_peek(&rays.gext[er]);
+                    while (e == EGR_EXT_LOCKED) __builtin_amdgcn_s_sleep(1), e = lds_peek(&rays.gext[er]);
+                    const uint32_t k = at - v.cand_cap;
+                    if (e < EGR_EXT_NONE - 1u && k < EGR_EXT_BLOCK) {
+                        v.ext_keys[(size_t)e * EGR_EXT_BLOCK + k] = t;
+                        v.ext_vals[(size_t)e * EGR_EXT_BLOCK + k] = make_float2(alpha, u2f(pidx));
+                    } else {
+                        g_over = true;
+                    }
+                }
+            }
+        }
+        // ---------------- work off: walk batch
+        if (npop != 0u) {
+#pragma unroll
+            for (int u = 0; u < EGR_GPOP; u++) {
+                const uint32_t rtag = pw[u] & 0xFC000000u; // the pair's ray, in place
+                const float4 q1 = rays.rayp[pw[u] >> 26][1], q2 = rays.rayp[pw[u] >> 26][2];
+                const uint4 sl = sl_[u];
+                // (masks built on the scalar side: one ballot of the box test, one of the leaf bit; an unpopped slot is an empty slot)
+                const bool hit = (SENT ? qslab_hit(sl, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), seg_lo, seg_hi) : qslab_hit_inframe(sl, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), seg_lo, seg_hi)) & (sl.w != EGR_EMPTY_SLOT);
+                const bool leaf = (int)sl.w < 0;
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit), lm = __builtin_amdgcn_ballot_w64(leaf);
+                const unsigned long long im = hm & ~lm, fm = hm & lm;
+                const uint32_t at = top + __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+                if (top + (uint32_t)EGR_WAVE <= (uint32_t)EGR_PSTK) { // wave-uniform: every push of this batch stays in the LDS part (the usual case)
+                    if (hit & !leaf) mine.pstk[at] = rtag | sl.w;
+                    top += (uint32_t)__popcll(im);
+                } else {
+                    if (hit & !leaf) {
+                        if (at < (uint32_t)EGR_PSTK) mine.pstk[at] = rtag | sl.w;
+                        else if (at - EGR_PSTK < GSTK_CAP) gstk[at - EGR_PSTK] = rtag | sl.w;
+                        else g_over = true;
+                    }
+                    top = min(top + (uint32_t)__popcll(im), (uint32_t)EGR_PSTK + GSTK_CAP);
+                }
+                if (hit & leaf) mine.lbuf[nl + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = rtag | (sl.w & ~EGR_LEAF_FLAG);
+                nl += (uint32_t)__popcll(fm);
+            }
+        }
+        wave_sync();
+#ifdef EGR_WALK_STATS
+        st.tall += (lane == 0 && top >= (uint32_t)EGR_DONATE_MIN) ? 1u : 0u;
+#endif
+        if constexpr (TEAM > 1) {
+            // a team mate looks for work and this stack is long: its lower half goes on offer
+            if (uniform_u32(idle_seen) != 0u && top >= (uint32_t)EGR_DONATE_MIN && top <= (uint32_t)EGR_PSTK && uniform_u32(lds_peek(&team.box_count[self])) == 0u) {
+                // EVERY OTHER pair of the lower part of the stack goes, the rest moves down. Both halves then hold subtrees of every size (the
+                // bottom holds the pairs nearest the root, i.e. the largest subtrees still to walk, the top the crumbs of the subtree the wave
+                // is in). Measured on rank 0 of an emulated 8-way partition: offers from the top shortened the heaviest walk by a quarter at
+                // best; offers of the bottom half left the owner waiting for its helpers for as long as its own half had taken.
+                const uint32_t give = min(top >> 1, (uint32_t)EGR_BOX);
+                for (uint32_t base = 0u; base < top; base += EGR_WAVE) {
+                    const uint32_t i = base + (uint32_t)lane;
+                    const uint32_t x = mine.pstk[min(i, (uint32_t)EGR_PSTK - 1u)];
+                    wave_sync();
+                    if (i < 2u * give) {
+                        if (i & 1u) team.box[self][i >> 1] = x;
+                        else mine.pstk[i >> 1] = x;
+                    } else if (i < top) mine.pstk[i - give] = x;
+                }
+                top -= give;
+                wave_sync();
+                if (lane == 0) lds_poke(&team.box_count[self], give | (lds_peek(&team.ctx[self][4]) << 16));
+#ifdef EGR_WALK_STATS
+                st.offers += (lane == 0);
+#endif
+            }
+        }
+    }
+}
+
+// A turn of a wave that looks for work: take an offer of a team mate and walk it - on this wave's own stack and leaf buffer, against the
+// ray table, per-ray counters and candidate lists of the wave whose rays the pairs belong to (pair_walk<.., HELPER>; ONE generic instance:
+// sentinel-aware, any segment). Returns false when there was no offer. The caller counts itself in team.hungry while it looks.
+template <bool CUBE, int TEAM> EGR_DI bool team_help(const DeviceView &v, const FwdConst &fc, WalkShared *wsh, TeamShared<TEAM> &team, const int wv, const uint32_t slot0, bool &g_over) {
+    const int lane = threadIdx.x & (EGR_WAVE - 1);
+    for (int dlt = 1; dlt < TEAM; dlt++) {
+        const int w = (wv + dlt) % TEAM;
+        uint32_t k = 0u, o = 0u;
+        if (lane == 0) {
+            const uint32_t c = lds_peek(&team.box_count[w]);
+            if (c != 0u && !(c & EGR_BOX_CLAIMED)) {
+                o = (c >> 16) & 0xFFu;
+                atomicAdd(&team.busy[o], 1u); // first: the rays' owner must never see "nobody busy" while these pairs are open
+                if (atomicCAS(&team.box_count[w], c, c | EGR_BOX_CLAIMED) == c) k = c & 0xFFFFu; // (ctx[w] cannot change while an offer of w is open)
+                else atomicSub(&team.busy[o], 1u);
+            }
+        }
+        k = uniform_u32(k);
+        if (k == 0u) continue;
+        const int owner = (int)uniform_u32(o);
+        if (lane == 0) atomicSub(&team.hungry, 1u);
+        WalkShared &mine = wsh[wv];
+        for (uint32_t i = (uint32_t)lane; i < k; i += EGR_WAVE) mine.pstk[i] = team.box[w][i];
+        const uint32_t c0 = uniform_u32(lds_peek(&team.ctx[w][0])), c1 = uniform_u32(lds_peek(&team.ctx[w][1])), c2 = uniform_u32(lds_peek(&team.ctx[w][2])), c3 = uniform_u32(lds_peek(&team.ctx[w][3]));
+        // this wave's own offers (it may pass on part of what it took) describe the same walk; its last offer may still be on its way out
+        while (uniform_u32(lds_peek(&team.box_count[wv])) != 0u) __builtin_amdgcn_s_sleep(1);
+        if (lane == 0) lds_poke(&team.ctx[wv][0], c0), lds_poke(&team.ctx[wv][1], c1), lds_poke(&team.ctx[wv][2], c2), lds_poke(&team.ctx[wv][3], c3), lds_poke(&team.ctx[wv][4], (uint32_t)owner);
+        wave_sync();
+        if (lane == 0) lds_poke(&team.box_count[w], 0u); // w may offer the next batch
+        const int step = (int)(c0 & 0xFFu), seg = (int)(c0 >> 8);
+        const size_t scratch0 = ((size_t)slot0 + (size_t)owner) * EGR_WAVE; // the OWNER's candidate lists
+        uint32_t *gstk = v.stack_spill + ((size_t)slot0 + (size_t)wv) * EGR_GSTK * EGR_WAVE; // this wave's own spill column
+        WalkStats st;
+        pair_walk<true, false, CUBE, TEAM>(v, fc, mine, wsh[owner], team, wv, scratch0, gstk, step, seg, u2f(c1), u2f(c2), u2f(c3), k, g_over, st);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the list entries written for the owner
+#ifdef EGR_WALK_STATS
+        if (lane == 0) atomicAdd(v.control + CW_DBG3 + 13, 1u), atomicAdd(v.control + CW_DBG3 + 14, st.inner);
+#endif
+        if (lane == 0) atomicSub(&team.busy[owner], 1u), atomicAdd(&team.hungry, 1u);
+        return true;
+    }
+    return false;
+}
+// ... for as long as `wanted()` says (wave-uniform): the waiting loop of an owner whose walk still has helpers, and of a wave without tiles.
+template <bool CUBE, int TEAM, class F> EGR_DI void team_help_while(const DeviceView &v, const FwdConst &fc, WalkShared *wsh, TeamShared<TEAM> &team, const int wv, const uint32_t slot0, bool &g_over, F wanted) {
+    const int lane = threadIdx.x & (EGR_WAVE - 1);
+    if (!wanted()) return;
+    if (lane == 0) atomicAdd(&team.hungry, 1u);
+    while (wanted())
+        if (!team_help<CUBE, TEAM>(v, fc, wsh, team, wv, slot0, g_over)) __builtin_amdgcn_s_sleep(4);
+    if (lane == 0) atomicSub(&team.hungry, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // per-launch prologue: Raytracer::raytrace host part (raytracer.cpp:82-86), on the device, no host sync
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_prologue(DeviceView v, int grads) {
@@ -285,15 +649,16 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
 #ifndef EGR_FWD_WAVES
 #define EGR_FWD_WAVES 4 // waves per SIMD the forward chain is built for (register budget 512 / EGR_FWD_WAVES)
 #endif
-template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(EGR_FWD_WAVES, EGR_FWD_WAVES))) k_forward_chain(DeviceView v) {
+template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribute__((amdgpu_waves_per_eu(EGR_FWD_WAVES, EGR_FWD_WAVES))) k_forward_chain(DeviceView v) {
 #include "forward_decl.inc"
-    __shared__ uint32_t wc[4 * EGR_NSTEPS]; // this wave's ray / candidate / composited / accepted counts per step
     if (lane < 4 * EGR_NSTEPS) wc[lane] = 0u;
-    __syncthreads();
+    if (threadIdx.x == 0) team.done = 0u, team.hungry = 0u;
+    if (threadIdx.x < TEAM) team.box_count[threadIdx.x] = 0u, team.busy[threadIdx.x] = 0u;
+    __syncthreads(); // the kernel's only workgroup barrier: from here on the waves of a team run independently
     uint32_t cur_q = blockIdx.x & 7u;
 
     for (;;) {
-        const uint32_t tq = wave_next_task(v.queues, v.task_count, cur_q);
+        const uint32_t tq = slot < v.num_slots ? wave_next_task(v.queues, v.task_count, cur_q, lane) : 0xFFFFFFFFu;
         if (tq == 0xFFFFFFFFu) break;
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9 // diagnostic build: stamps of the WHOLE chain of a task (start, end of every step) in its first pixels
         unsigned long long chain_t[EGR_NSTEPS + 1] = {__builtin_amdgcn_s_memrealtime(), 0ull, 0ull, 0ull};
@@ -321,10 +686,17 @@ template <bool GRADS, bool CUBE> __global__ void __launch_bounds__(EGR_WAVE) __a
         }
 #endif
     }
-    __syncthreads();
+    wave_sync();
     if (lane < EGR_NSTEPS) {
         add64(v.control, CW_RAYS + 2 * lane, wc[4 * lane]), add64(v.control, CW_CAND + 2 * lane, wc[4 * lane + 1]), add64(v.control, CW_COMP + 2 * lane, wc[4 * lane + 2]);
         add64(v.control, CW_ACCEPTED + 2 * lane, wc[4 * lane + 3]);
+    }
+    if (TEAM > 1 && v.team_help) {
+        // no tiles left for this wave: it helps its team mates with the walks of theirs until all of them are through
+        if (lane == 0) atomicAdd(&team.done, 1u);
+        bool h_over = false;
+        team_help_while<CUBE, TEAM>(v, fc, wsh_all, team, wv, blockIdx.x * (uint32_t)TEAM, h_over, [&]() { return uniform_u32(lds_peek(&team.done)) < (uint32_t)TEAM; });
+        if (h_over) atomicOr(v.control + CW_STATUS, EGR_STATUS_CANDIDATE_OVERFLOW);
     }
 }
 
@@ -444,7 +816,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
     uint32_t records = 0u; // 64-B gradient records this wave sent: bounce hits, primary hits without a table slot (two each), flushed table slots (two each) (egr_counters::bucket_records)
 
     for (;;) {
-        const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q);
+        const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q, lane);
         if (tq == 0xFFFFFFFFu) break;
         bool table_dirty = false; // (wave-uniform) a bounce step used the table's memory for its queues
         for (int step = num_bounces; step >= 1; step--) {
@@ -655,8 +1027,13 @@ void egr_trace_alloc(egr_context *c) {
     hipDeviceProp_t prop;
     EGR_HIP(hipGetDeviceProperties(&prop, c->device));
     int per_cu = 0; // the forward chain is built for four waves per SIMD (faster with more waves in flight even with spills)
-    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_forward_chain<true, false>, EGR_WAVE, 0));
+    EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_forward_chain<true, false, 1>), EGR_WAVE, 0));
     per_cu = std::max(1, std::min(32, per_cu));
+    {
+        int teams = 0; // the team build holds whole teams
+        EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&teams, (k_forward_chain<true, false, EGR_TEAM>), EGR_WAVE * EGR_TEAM, 0));
+        c->team_waves_per_cu = std::max(1, teams) * EGR_TEAM;
+    }
     if (getenv("EGR_DEBUG_OCCUPANCY")) {
         int bwd = 0;
         EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, k_backward_chain, EGR_WAVE, 0));
@@ -664,7 +1041,7 @@ void egr_trace_alloc(egr_context *c) {
     }
     if (const char *e = getenv("EGR_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // tuning knob
     uint32_t resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
-    c->num_slots = std::max(1u, std::min(resident, c->num_tasks_total));
+    c->num_slots = std::max((uint32_t)EGR_TEAM, std::min(resident, (c->num_tasks_total + EGR_TEAM - 1u) / EGR_TEAM * EGR_TEAM)); // whole teams (the workgroups of the forward chain's team build)
     // forward budget: the reference's ppll_forward_size entries x 36 B, spent on (key 4 B + value 8 B) x 64 lanes x cap per slot
     // (the leaf pairs awaiting evaluation live in LDS since the pair walk: no queue in global memory)
     double fwd_bytes = (double)c->fwd_capacity * 36.0;
@@ -717,11 +1094,13 @@ DeviceView egr_make_view(const egr_context *c) {
     // (pair walk), so exactly tied depths may composite in another order than with 8x8 tasks (documented deviation (a)).
     const uint32_t tiles = egr_num_tasks_for_rank(c);
     uint32_t rpt = c->rays_per_task == 16 || c->rays_per_task == 32 || c->rays_per_task == 64 ? (uint32_t)c->rays_per_task
-                   : (c->world > 1 && tiles < 2u * c->num_slots ? 32u : 64u);
+                   : (c->world > 1 && tiles < 2u * c->num_slots && c->team_help != 1 ? 32u : 64u); // (with team help the heavy tile's walk is shared anyway, and whole 8x8 tiles keep all lanes busy in the per-ray phases: 3.08-3.12 against 3.17-3.21 ms trained-like, 3.50-3.55 against 3.48-3.51 ms dense-init per iteration of rank 0 of 8)
     v.rays_per_task = rpt, v.task_shift = rpt == 64u ? 2u : rpt == 32u ? 3u : 4u;
     v.num_tasks = tiles << (v.task_shift - 2u);
     v.task_begin = 0, v.task_count = v.num_tasks, v.queues = c->queues, v.num_strands = (uint32_t)c->strands;
     v.task_macro = c->task_macro;
+    // (help changes the ORDER in which a ray's candidates enter its list, never the set: off unless the caller asks - egr_set_team_help)
+    v.team_help = EGR_TEAM > 1 && c->team_help == 1 ? 1 : 0;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
@@ -767,13 +1146,20 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
             w.stack_spill += slot0 * EGR_GSTK * EGR_WAVE;
             const dim3 sgrid(std::max(1u, std::min(c->num_slots, w.task_count)));
             egr_stamp_begin(c, "forward_chain", ls);
-            if (grads) {
-                if (v.cube_mode) hipLaunchKernelGGL((k_forward_chain<true, true>), sgrid, block, 0, ls, w);
-                else hipLaunchKernelGGL((k_forward_chain<true, false>), sgrid, block, 0, ls, w);
-            } else {
-                if (v.cube_mode) hipLaunchKernelGGL((k_forward_chain<false, true>), sgrid, block, 0, ls, w);
-                else hipLaunchKernelGGL((k_forward_chain<false, false>), sgrid, block, 0, ls, w);
-            }
+            // (the chain exists as single-wave workgroups and as teams of EGR_TEAM waves: launches with egr_set_team_help(1) take the teams)
+            auto launch_forward = [&](auto team_tag) {
+                constexpr uint32_t T = (uint32_t) decltype(team_tag)::value;
+                const dim3 fgrid((sgrid.x + T - 1u) / T), fblock(EGR_WAVE * T); // (num_slots is a multiple of EGR_TEAM: every wave of a team has its scratch)
+                if (grads) {
+                    if (v.cube_mode) hipLaunchKernelGGL((k_forward_chain<true, true, (int)T>), fgrid, fblock, 0, ls, w);
+                    else hipLaunchKernelGGL((k_forward_chain<true, false, (int)T>), fgrid, fblock, 0, ls, w);
+                } else {
+                    if (v.cube_mode) hipLaunchKernelGGL((k_forward_chain<false, true, (int)T>), fgrid, fblock, 0, ls, w);
+                    else hipLaunchKernelGGL((k_forward_chain<false, false, (int)T>), fgrid, fblock, 0, ls, w);
+                }
+            };
+            if (v.team_help) launch_forward(std::integral_constant<int, EGR_TEAM>{});
+            else launch_forward(std::integral_constant<int, 1>{});
             egr_stamp_end(c, ls);
             if (grads) {
                 egr_stamp_begin(c, "backward_chain", ls);

@@ -80,7 +80,7 @@ class GaussianRaytracer:
                       "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final")
 
     def __init__(self, pc, image_width: int, image_height: int, ppll_forward_size=None, ppll_backward_size=None, rank=0, world_size=1,
-                 gather_buffers=None):
+                 gather_buffers=None, team_help=False):
         self.image_width, self.image_height = image_width, image_height
         # partitioned evaluation renders: which framebuffer outputs `gather_outputs` completes on every rank (default: all ten) and
         # whether every no-grad call does it (False: the caller gathers when it needs the images, e.g. once after the 128 accumulated
@@ -99,6 +99,8 @@ class GaussianRaytracer:
             self.cuda_module.resize(n)
         self.rank, self.world_size = rank, world_size
         self.import_grads = True  # False: a fused host step (trainer.FusedTrainStep) imports the raytracer gradients itself
+        if team_help:  # several waves on one heavy tile (egr_set_team_help): shortens the tail of a partition's rank; forward outputs then depend on timing in their last bits
+            self.cuda_module.set_team_help(True)
         if world_size > 1:
             self.cuda_module.set_partition(rank, world_size)
             self.cuda_module.use_grad_delta(True)  # launches accumulate into a per-launch buffer: see all_reduce_grads

@@ -195,6 +195,14 @@ int egr_set_strands(egr_context *ctx, int strands);
  * that trace single macro tiles through egr_set_partition pin the shape of the run they compare with. Returns 1 for other values. */
 int egr_set_rays_per_task(egr_context *ctx, int rays_per_task);
 
+/* Team help (not in the reference): the forward chain's workgroups are teams of waves with a shared LDS; with help on, a wave that has no tile
+ * left (or waits for its own helpers) walks (ray, node) pairs that a team mate with a long pair stack puts on offer - several waves on one heavy
+ * tile, for ranks of a multi-GPU partition whose launch lasts as long as their heaviest tile. Help changes the ORDER in which a ray's candidates
+ * enter its list, never the set: the per-pixel statistics stay equal, the total transmittance product rounds differently in its last bit and
+ * exactly tied depths may composite in another order from run to run (deviation (a)). 0 = off (default: forward outputs are
+ * reproducible bit for bit), 1 = on; also env EGR_TEAM_HELP at creation. Returns 1 for other values. */
+int egr_set_team_help(egr_context *ctx, int on);
+
 /* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace.
  * ABI: egr_counters only ever GROWS AT ITS END (version string of egr_version() bumps with it). egr_get_counters writes
  * sizeof(egr_counters) of THIS header; a host compiled against an older header passes its own sizeof to egr_get_counters_ex, which

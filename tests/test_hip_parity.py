@@ -607,6 +607,44 @@ def test_strands_do_not_change_results(ren, orc, syn):
         m.set_strands(99)
 
 
+def test_team_help_changes_the_list_order_only(ren, orc, syn):
+    """egr_set_team_help(1): waves without tiles walk (ray, node) pairs their team mates offer (several waves on one heavy tile). The SET of
+    candidates of every ray stays what it was - both per-pixel statistics and every counter equal the run without help - only the order in
+    which they enter the ray's list may change: the total-transmittance product rounds differently in its last bit, everything else follows
+    from that (a small image leaves most waves of every team without a tile, so help is the rule here, not the exception)."""
+    W, H = 96, 64
+    g = syn.make_scene(4000, "trained", seed=21)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    rt, _ = make_pair(ren, orc, g, cam, W, H)  # (the run without help is the one the other tests hold against the oracle)
+    m = rt.cuda_module
+    res = {}
+    for help_on in (False, True, True):
+        m.set_team_help(help_on)
+        m.get_metadata().total_num_calls.zero_()  # same jitter / GGX random stream for all launches
+        with torch.no_grad():
+            rt(cam_obj(ren, cam))
+        img = hip_outputs(rt)
+        st = m.get_stats()
+        stats = (st.num_traversed_per_pixel.cpu().numpy().copy(), st.num_accumulated_per_pixel.cpu().numpy().copy())
+        m.get_metadata().total_num_calls.zero_()
+        run_grad(ren, rt, cam_obj(ren, cam, tg))
+        res.setdefault(help_on, []).append((img, hip_grads(rt), list(m.get_counters()[:9]), stats, int(m.get_counters()[11])))
+    m.set_team_help(False)
+    ref = res[False][0]
+    worst = 0.0
+    for run in res[True]:
+        assert run[4] == 0 and run[2] == ref[2], (run[2], ref[2])
+        assert np.array_equal(run[3][0], ref[3][0]) and np.array_equal(run[3][1], ref[3][1])  # candidates counted / hits composited per pixel
+        for k in OUT_KEYS:
+            d = np.abs(run[0][k] - ref[0][k]).max() / (np.abs(ref[0][k]).max() + 1e-30)
+            worst = max(worst, d)
+            assert d < 2e-5, (k, d)
+        for k in GRAD_KEYS:
+            assert np.abs(run[1][k] - ref[1][k]).max() / (np.abs(ref[1][k]).max() + 1e-30) < 1e-4, k
+    print(f"REPORT team help: worst output difference against the run without help {worst:.2e} of the buffer's maximum")
+
+
 # ------------------------------------------------------------------------------------------------ full size
 def test_full_size_properties_1080p_1M(ren, orc, syn):
     """BASELINE config C (1080p, 1M Gaussians): size-independent properties instead of a full oracle run."""

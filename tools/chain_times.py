@@ -6,6 +6,8 @@ W, H, N = 1920, 1080, 1_000_000
 g = syn.make_scene(N, os.environ.get("VARIANT", "init"), seed=0); cam = syn.default_camera()
 rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000); m = rt.cuda_module
 m.set_strands(1)
+world = int(os.environ.get("EMU_WORLD", "1"))
+if world > 1: m.set_partition(int(os.environ.get("EMU_RANK", "0")), world)  # (build / run with EGR_RAYS_PER_TASK=64: the stamps sit in the first pixels of 8x8 tiles)
 camera = ren.camera_from_c2w(cam["origin"], cam["c2w"], cam["fov"])
 for _ in range(20):
     with torch.no_grad(): rt(camera)
@@ -16,9 +18,9 @@ for call in [int(x) for x in os.environ.get("CALLS", "10,11").split(",")]:
     t = m.get_stats().num_traversed_per_pixel.view(H // 8, 8, W // 8, 8)[:, 0, :, :4].cpu().numpy().astype(np.int64).reshape(-1, 4) * 0.01  # us
     d = np.diff(t, axis=1)  # per step
     tot = t[:, 3] - t[:, 0]
-    ok = (d >= 0).all(1)
+    ok = (d >= 0).all(1) & (t[:, 0] > 0) & (tot > 0)  # (tiles of other ranks carry no stamps)
     o = np.argsort(-np.where(ok, tot, 0))[:6]
-    print(f"call {call}: heaviest chains (us: total | step 0, 1, 2):", [(round(float(tot[i]), 1), [round(float(x), 1) for x in d[i]], "tile", int(i % (W // 8)), int(i // (W // 8))) for i in o], "mean", round(float(tot[ok].mean()), 1), flush=True)
+    print(f"call {call}: heaviest chains (us: total | step 0, 1, 2):", [(round(float(tot[i]), 1), [round(float(x), 1) for x in d[i]], "tile", int(i % (W // 8)), int(i // (W // 8))) for i in o], "mean", round(float(tot[ok].mean()), 1), "mean per step", [round(float(x), 1) for x in d[ok].mean(0)], "tiles", int(ok.sum()), flush=True)
     # how full the wave slots are over the kernel, and what other tile orders of the SAME chain durations would give (list scheduling)
     import heapq
     start, end = t[ok, 0], t[ok, 3]

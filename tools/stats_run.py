@@ -6,6 +6,7 @@ VARIANT=os.environ.get("VARIANT","trained")
 g=syn.make_scene(N,VARIANT,seed=0); cam=syn.default_camera(); pc=ren.GaussianParams(g)
 rt=ren.GaussianRaytracer(pc,W,H,ppll_forward_size=400_000_000,ppll_backward_size=300_000_000); m=rt.cuda_module
 camera=ren.camera_from_c2w(cam["origin"],cam["c2w"],cam["fov"])
+if int(os.environ.get("EMU_WORLD","1"))>1: m.set_strands(1); m.set_partition(int(os.environ.get("EMU_RANK","0")),int(os.environ["EMU_WORLD"]))
 if os.environ.get("GRADS"):
     tg=syn.make_targets(W,H)
     camera=ren.camera_from_c2w(cam["origin"],cam["c2w"],cam["fov"],**{k+"_image": torch.tensor(v).cuda().moveaxis(-1,0).contiguous() for k,v in tg.items()})

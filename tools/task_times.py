@@ -23,10 +23,14 @@ t0 = st.num_traversed_per_pixel.view(H, W)[::RY, ::8].cpu().numpy().astype(np.in
 t1 = st.num_accumulated_per_pixel.view(H, W)[::RY, ::8].cpu().numpy().astype(np.int64).ravel()
 tm = st.num_traversed_per_pixel.view(H, W)[::RY, 1::8].cpu().numpy().astype(np.int64).ravel()
 own = t1 > t0
+def px(img, k): return img.view(H, W)[::RY, k::8].cpu().numpy().astype(np.int64).ravel()[own]
+extra = {"walk batches": px(st.num_traversed_per_pixel, 2), "evaluation batches": px(st.num_accumulated_per_pixel, 2), "offers": px(st.num_traversed_per_pixel, 3), "tall-stack batches": px(st.num_accumulated_per_pixel, 3),
+         "us waiting for helpers (helping meanwhile)": px(st.num_traversed_per_pixel, 4) * 0.01, "longest list": px(st.num_accumulated_per_pixel, 4)}
 t0, t1, tm = t0[own], t1[own], tm[own]
 walk, sel = (tm - t0) * 0.01, (t1 - tm) * 0.01
 order = np.argsort(-(t1 - t0))[:12]
 print("heaviest tasks (us): total / walk / selection+compositing:", [(round(float((t1 - t0)[i]) * 0.01, 1), round(float(walk[i]), 1), round(float(sel[i]), 1)) for i in order])
+for k, a in extra.items(): print(f"   {k}: heaviest tasks", [round(float(a[i]), 1) for i in order], "| mean over all tasks", round(float(a.mean()), 1))
 print("all tasks: walk share of the task time: mean", float(walk.sum() / (walk.sum() + sel.sum())))
 base = t0.min()
 s, e = (t0 - base) * 0.01, (t1 - base) * 0.01  # us
