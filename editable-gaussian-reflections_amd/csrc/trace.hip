@@ -3,14 +3,17 @@
 //
 // Structure (MI355X-first; nothing here is a translation of the OptiX pipeline; DESIGN.md 4 has the measurements):
 //   * one wave64 = one 8x8 pixel tile, one lane = one ray; PERSISTENT waves pull tiles from 8 XCD-affine atomic queues
-//     (ragged per-ray work: 1..1000s of candidates), one workgroup = one wave so waves never wait on each other;
+//     (ragged per-ray work: 1..1000s of candidates); waves never wait on each other (no workgroup barrier after the first instruction);
 //   * a tile runs through ALL its steps in one go (k_forward_chain: trace, step epilogue, trace, ...; k_backward_chain), so
 //     a launch pays the tail of its heaviest tile once per chain, not once per step. The per-step source lives in
 //     forward_task.inc / backward_task.inc / egr_epilogue.hpp. Per-ray state lives in a task-linear SoA buffer (fully coalesced);
-//   * the 8-wide BVH (128-B line-sized nodes, 16-bit child boxes) is walked as ONE packet by coherent tiles (primary rays:
-//     scalar loads, every lane tests its own ray) and by GROUPS OF EIGHT LANES PER RAY by incoherent tiles (lane m tests
-//     child m; ballot compaction onto a per-ray LDS stack and leaf queue; groups take rays from a shared per-tile list);
-//     traversal (phase A) and candidate evaluation (phase B) are decoupled;
+//   * the 8-wide BVH (128-B line-sized nodes, 16-bit child boxes) is walked by PRIMARY tiles as one FRUSTUM (all 64 rays leave the camera
+//     origin: one interval test per child slot for the whole tile, eight nodes per iteration; the leaves found are evaluated one after
+//     the other, records through the scalar cache, every lane for its own ray) and by BOUNCE tiles as PAIRS (one wave-wide LIFO of
+//     (ray, node) pairs and one buffer of (ray, leaf) pairs in LDS: lane m of group g tests child slot m of the g-th popped node, ballots
+//     compact the hits, and 64 leaf pairs at a time are evaluated with one lane per pair) - pair_walk below, frustum walk in forward_task.inc;
+//   * the forward chain exists as single-wave workgroups and as TEAMS of waves with a shared LDS in which waves without tiles walk pairs
+//     their team mates offer (egr_set_team_help: several waves on one heavy tile, for under-filled ranks of a multi-GPU partition);
 //   * the reference's global per-pixel linked list (one same-address atomic per candidate, 36 B entries, pointer chasing)
 //     is replaced by a per-resident-wave candidate scratch, one contiguous run per lane ([lane][k]) with bump-allocated
 //     extension blocks for the rare long list; it is reused tile after tile;
