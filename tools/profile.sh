@@ -11,7 +11,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 # one process per opacity variant, so that a kernel's average in the stats file belongs to ONE workload (the headline line first);
 # 400+ launches, so that the first few cold ones (clock ramp: up to 3x the steady duration) do not carry the average
 for VAR in init trained; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$VAR -o t -- python bench.py --strands 1 --steps 100 --warmup 300 --prewarm-seconds 3 --no-cpu-baseline --no-second-variant --variant $VAR > $OUT/bench_under_rocprof_$VAR.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$VAR -o t -- python bench.py --strands 1 --steps 100 --warmup 300 --prewarm-seconds 3 --no-cpu-baseline --no-second-variant --primary-steps 0 --variant $VAR > $OUT/bench_under_rocprof_$VAR.log 2>&1
   grep -a "^{" $OUT/bench_under_rocprof_$VAR.log | tail -1 > $OUT/bench_line_under_rocprof_$VAR.json
   find $OUT/trace_$VAR -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_$VAR.csv \;
 done
