@@ -713,6 +713,9 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 #define EGR_GT_SLOTS 94 // (round 4: 94 - what fits twelve waves per CU since the bounce queues share the table's memory; it was 64) slots of the primary step's LDS table (any count >= 64; multiply-shift hash). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
                         // per CU) and a hit that finds no slot leaves as wide adds anyway (trained 3.46 -> 3.25 ms, dense-init 7.7 -> 4.9 ms)
 #endif
+#ifndef EGR_FLUSH_WHEN_FULL
+#define EGR_FLUSH_WHEN_FULL 1 // primary backward: a hit that finds no table slot makes the wave flush the table and look again (0: such hits leave as records of their own)
+#endif
 #ifndef EGR_PRIMARY_TABLE
 #define EGR_PRIMARY_TABLE 1 // 0 (measured: 4.8 instead of 3.3 ms): primary hits skip the LDS table and leave as records like bounce hits
 #endif
