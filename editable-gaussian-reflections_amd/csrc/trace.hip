@@ -710,8 +710,9 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 // so per-hit contributions are first summed in a per-wave LDS hash table (ds_add_f32, open addressing on the
 // record index) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
 #ifndef EGR_GT_SLOTS
-#define EGR_GT_SLOTS 94 // (round 4: 94 - what fits twelve waves per CU since the bounce queues share the table's memory; it was 64) slots of the primary step's LDS table (any count >= 64; multiply-shift hash). 64 beats 128 and 256: the table costs LDS (10 -> 12 waves
-                        // per CU) and a hit that finds no slot leaves as wide adds anyway (trained 3.46 -> 3.25 ms, dense-init 7.7 -> 4.9 ms)
+#define EGR_GT_SLOTS 80 // slots of the primary step's LDS table (any count >= 64; multiply-shift hash). Since a full table is flushed and refilled
+                        // (EGR_FLUSH_WHEN_FULL, round 4) a smaller one is as good: 64 / 72 / 80 / 94 slots -> 3.02 / 3.05 / 3.01-3.03 / 3.11 ms backward chain
+                        // dense-init (same box). Before that: 94 beat 64 (hits without a slot left as records of their own), 128 and 256 cost waves per CU
 #endif
 #ifndef EGR_FLUSH_WHEN_FULL
 #define EGR_FLUSH_WHEN_FULL 1 // primary backward: a hit that finds no table slot makes the wave flush the table and look again (0: such hits leave as records of their own)
@@ -790,7 +791,7 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
 // last bounce first (15 gradient components per hit, straight out as wide adds), then the primary step (22 components through
 // the LDS table). Per-step code: backward_task.inc.
 #ifndef EGR_COMBINE_MASK
-#define EGR_COMBINE_MASK 1 // primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
+#define EGR_COMBINE_MASK 0 // (round 4, with the flushed table: no level beyond lane ^ 1, lane ^ 8 - 2.95-2.97 against 3.01-3.03 ms with lane ^ 2; it was 1) primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
 #endif
 #ifndef EGR_BWD_COMPACT
 #define EGR_BWD_COMPACT 1 // bounce-step backward: per-ray suffix sums first, then the per-hit geometry with one lane per HIT (backward_task.inc)
