@@ -717,9 +717,6 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 #ifndef EGR_FLUSH_WHEN_FULL
 #define EGR_FLUSH_WHEN_FULL 1 // primary backward: a hit that finds no table slot makes the wave flush the table and look again (0: such hits leave as records of their own)
 #endif
-#ifndef EGR_BWD_PREFETCH
-#define EGR_BWD_PREFETCH 1
-#endif
 #ifndef EGR_PRIMARY_TABLE
 #define EGR_PRIMARY_TABLE 1 // 0 (measured: 4.8 instead of 3.3 ms): primary hits skip the LDS table and leave as records like bounce hits
 #endif
