@@ -232,12 +232,13 @@ EGR_DI bool hits_unit_cube_exact(f3 lo, f3 ld, float tmin, float tmax) {
 // ---------------------------------------------------------------------------------------------------------
 // A workgroup of the forward chain is a TEAM of EGR_TEAM waves. Every wave still owns its tiles alone (its own queue pulls, stack,
 // leaf buffer, ray table, candidate scratch: waves never wait for each other while there are tiles), but the LDS is shared, and that
-// is what lets SEVERAL WAVES WORK ON ONE HEAVY TILE: a wave that finds the task queue empty stays as a HELPER, and a wave whose pair
-// stack is long while a team mate idles puts the upper half of it (up to EGR_BOX pairs) on offer. The helper walks those pairs on its
-// own stack and leaf buffer against the OWNER's ray table, and its accepted candidates take slots of the owner's lists through the
-// owner's LDS counters - exactly what the owner would have done with them, in another order (the list order of a ray is an
-// implementation matter). A rank of an 8-way partition has one or two tiles per wave slot and its launch used to last
-// as long as ONE wave needed for the heaviest tile's walk.
+// is what lets SEVERAL WAVES WORK ON ONE HEAVY TILE: a wave that finds the task queue empty - or waits for the helpers of its own walk -
+// looks for OFFERS, and a walking wave whose pair stack is long while a team mate looks for work puts every other pair of the lower part
+// of it (up to EGR_BOX pairs) on offer. The taker walks those pairs on its own stack and leaf buffer against the OWNER's ray table, its
+// accepted candidates take slots of the owner's lists through the owner's LDS counters - exactly what the owner would have done with
+// them, in another order (the list order of a ray is an implementation matter) - and it may pass part of them on. A rank
+// of an 8-way partition has one tile per wave slot and its launch lasts as long as its heaviest tile's chain. Off unless
+// the caller asks (egr_set_team_help): a ray's list order then depends on timing.
 #ifndef EGR_TEAM
 #define EGR_TEAM 16 // waves per workgroup of the forward chain's team build: the chain exists twice, as teams of this size for launches with
                     // egr_set_team_help(1) and as single-wave workgroups for all others (a team's LDS stays allocated until its last wave
@@ -248,7 +249,7 @@ EGR_DI bool hits_unit_cube_exact(f3 lo, f3 ld, float tmin, float tmax) {
 #define EGR_BOX 128 // (ray, node) pairs one offer holds
 #endif
 #ifndef EGR_DONATE_MIN
-#define EGR_DONATE_MIN 96 // an owner offers half of its stack from this height on
+#define EGR_DONATE_MIN 96 // a walking wave offers half of its stack from this height on (48 ... 128 make no difference: sweeps r5k)
 #endif
 #define EGR_BOX_CLAIMED 0x80000000u
 #define EGR_EXT_LOCKED (EGR_EXT_NONE - 2u) // a wave of the team is fetching this ray's extension block right now
@@ -354,7 +355,7 @@ EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plan
 // The loop exists once per decode of the child boxes (SENT: out-of-frame sentinels or not, wave-uniform for the whole launch) and once more
 // for segment 0 without sentinels (SEG0; nearly every walk of a bounce step) - the choice is made once per walk instead of once per slot batch.
 // `mine`: stack and leaf buffer of the executing wave; `rays`: ray table, per-ray counters and (through scratch0) candidate lists of the
-// wave that OWNS the tile - the same wave unless HELPER. The owner enters with `top` pairs on mine.pstk, a helper with the pairs it took.
+// wave that OWNS the tile - the same wave unless the pairs were taken from an offer (team_help). The caller enters with `top` pairs on mine.pstk.
 template <bool SENT, bool SEG0, bool CUBE, int TEAM>
 EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine, WalkShared &rays, TeamShared<TEAM> &team, const int self, const size_t scratch0,
                       uint32_t *__restrict__ gstk, const int step, const int seg, const float seg_lo, const float seg_hi, const float near_plane, uint32_t top,
@@ -364,7 +365,7 @@ EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine,
     constexpr uint32_t GSTK_CAP = (uint32_t)EGR_GSTK * EGR_WAVE;
     const uint4 *__restrict__ wnodes = fc.wnodes;
     uint32_t nl = 0u; // wave-uniform height of the leaf buffer (top: of the pair stack)
-    uint32_t idle_seen = 0u;
+    uint32_t hungry_seen = 0u;
     for (;;) {
         // One iteration = (up to) one evaluation batch AND one walk batch: the record fetches of the batch of 64 leaf pairs and
         // the node fetches of the popped pairs are issued together, then both are worked off - a tile's critical path is its
@@ -409,7 +410,7 @@ EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine,
         const uint32_t npop = ((EGR_PIPELINE || !do_eval) && nl + (uint32_t)EGR_WALK_MAX_LEAVES <= (uint32_t)EGR_LBUF) ? min(top, 8u * (uint32_t)EGR_GPOP) : 0u;
         uint32_t pw[EGR_GPOP];
         uint4 sl_[EGR_GPOP];
-        if constexpr (TEAM > 1) idle_seen = lds_peek(&team.hungry); // (read with the stack: one LDS round trip)
+        if constexpr (TEAM > 1) hungry_seen = lds_peek(&team.hungry); // (read with the stack: one LDS round trip)
         if (npop != 0u) {
 #pragma unroll
             for (int u = 0; u < EGR_GPOP; u++) pw[u] = mine.pstk[min(top - 1u - min(grp + 8u * (uint32_t)u, top - 1u), (uint32_t)EGR_PSTK - 1u)];
@@ -512,7 +513,7 @@ EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine,
 #endif
         if constexpr (TEAM > 1) {
             // a team mate looks for work and this stack is long: its lower half goes on offer
-            if (uniform_u32(idle_seen) != 0u && top >= (uint32_t)EGR_DONATE_MIN && top <= (uint32_t)EGR_PSTK && uniform_u32(lds_peek(&team.box_count[self])) == 0u) {
+            if (uniform_u32(hungry_seen) != 0u && top >= (uint32_t)EGR_DONATE_MIN && top <= (uint32_t)EGR_PSTK && uniform_u32(lds_peek(&team.box_count[self])) == 0u) {
                 // EVERY OTHER pair of the lower part of the stack goes, the rest moves down. Both halves then hold subtrees of every size (the
                 // bottom holds the pairs nearest the root, i.e. the largest subtrees still to walk, the top the crumbs of the subtree the wave
                 // is in). Measured on rank 0 of an emulated 8-way partition: offers from the top shortened the heaviest walk by a quarter at
@@ -539,7 +540,7 @@ EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine,
 }
 
 // A turn of a wave that looks for work: take an offer of a team mate and walk it - on this wave's own stack and leaf buffer, against the
-// ray table, per-ray counters and candidate lists of the wave whose rays the pairs belong to (pair_walk<.., HELPER>; ONE generic instance:
+// ray table, per-ray counters and candidate lists of the wave whose rays the pairs belong to (ONE generic instance of pair_walk:
 // sentinel-aware, any segment). Returns false when there was no offer. The caller counts itself in team.hungry while it looks.
 template <bool CUBE, int TEAM> EGR_DI bool team_help(const DeviceView &v, const FwdConst &fc, WalkShared *wsh, TeamShared<TEAM> &team, const int wv, const uint32_t slot0, bool &g_over) {
     const int lane = threadIdx.x & (EGR_WAVE - 1);
