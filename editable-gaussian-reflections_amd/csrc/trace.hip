@@ -810,9 +810,11 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
     // the two queues of the bounce steps live in the table's memory: the table is empty (flushed, all zero) while a tile's bounce steps run -
     // they come before its primary step - and the words they dirtied are cleared again before that step (backward_task.inc). 2.75 KB less
     // LDS per wave: 94 table slots instead of 64 at the same twelve waves per CU.
-    static_assert(EGR_GT_STRIDE * EGR_GT_SLOTS >= 11 * EGR_WAVE, "the bounce queues must fit into the table");
-    uint2 *bitems = reinterpret_cast<uint2 *>(gt_vals);  // [4 x 64] bounce steps: (ray | row << 6, dL/dalpha) of the hits of a chunk of four rows
-    float *bdl = gt_vals + 8 * EGR_WAVE;                 // [3 x 64] bounce steps: the rays' radiance gradient
+#define EGR_BQ_FLOATS (25 * EGR_WAVE) // floats of the table's memory the bounce steps use
+    static_assert(EGR_GT_STRIDE * EGR_GT_SLOTS >= EGR_BQ_FLOATS, "the bounce queues must fit into the table");
+    uint4 *bitems = reinterpret_cast<uint4 *>(gt_vals);  // [4 x 64] bounce steps: (ray, dL/dalpha, record, weight) of the hits of a chunk of four rows
+    float *bdl = gt_vals + 16 * EGR_WAVE;                // [3 x 64] bounce steps: the rays' radiance gradient
+    float *bray = gt_vals + 19 * EGR_WAVE;               // [6 x 64] bounce steps: the rays (origin, direction)
 #endif
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < EGR_GT_STRIDE * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
@@ -826,6 +828,11 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
     for (;;) {
         const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q, lane);
         if (tq == 0xFFFFFFFFu) break;
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8 // diagnostic build: stamps of a task's BACKWARD chain in its first pixels (tools/bwd_times.py)
+        const unsigned long long bw_t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long bw_t1 = 0ull;
+        uint32_t bw_rows0 = 0u;
+#endif
         bool table_dirty = false; // (wave-uniform) a bounce step used the table's memory for its queues
         for (int step = num_bounces; step >= 1; step--) {
             constexpr bool PRIMARY = false;
@@ -836,9 +843,12 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
 #if EGR_BWD_COMPACT
         if (table_dirty) {
             __syncthreads();
-            for (int s = lane; s < 11 * EGR_WAVE; s += EGR_WAVE) gt_vals[s] = 0.0f;
+            for (int s = lane; s < EGR_BQ_FLOATS; s += EGR_WAVE) gt_vals[s] = 0.0f;
             __syncthreads();
         }
+#endif
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
+        bw_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
         {
             constexpr bool PRIMARY = true;
@@ -847,6 +857,16 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
 #include "backward_task.inc"
             } while (false);
         }
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
+        {
+            const unsigned long long bw_t2 = __builtin_amdgcn_s_memrealtime();
+            const TaskGeom btg = task_geom(v, v.task_begin + tq, lane);
+            if (btg.inside) {
+                if (lane == 0) v.stats.num_traversed_per_pixel[btg.pixel_id] = (int32_t)(bw_t0 & 0x7FFFFFFFull), v.stats.num_accumulated_per_pixel[btg.pixel_id] = (int32_t)(bw_t2 & 0x7FFFFFFFull);
+                if (lane == 1) v.stats.num_traversed_per_pixel[btg.pixel_id] = (int32_t)(bw_t1 & 0x7FFFFFFFull), v.stats.num_accumulated_per_pixel[btg.pixel_id] = (int32_t)bw_rows0;
+            }
+        }
+#endif
     }
     if (lane == 0 && records) atomicAdd(v.control + CW_BUCKET_RECORDS, records);
 }
