@@ -727,6 +727,7 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 // component order of the LDS table, of a wide-add record (first 15) and of a gradient row (DeviceView::grad_rows)
 enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_WEIGHT = 14, GC_NORMAL = 15, GC_F0 = 18, GC_ROUGH = 21 };
 #define EGR_ROW_STRIDE 32 // floats per gradient row: one 128-B line per gaussian
+#define EGR_BWD_SYNC() wave_sync() // the backward chain's waves run independently (like the forward's): phases that exchange data through LDS within ONE wave need no more than program order
 
 // SIXTEEN LANES PER RECORD add the 15 values of every lane with `ok` to components base .. base+14 of its gaussian's
 // gradient row - one 64-B atomic request per record, nothing returned, so the requests drain behind the wave's arithmetic
@@ -734,7 +735,7 @@ enum : int { GC_OPA = 0, GC_SCALE = 1, GC_MEAN = 4, GC_ROT = 7, GC_RGB = 11, GC_
 // per-block buckets + counting-sort reduce, per-wave record logs + an apply kernel - are measured in DESIGN.md 4 and gone).
 // Wave-uniform call; `stage` = 64 x 4 float4.
 EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const float (&r)[15], uint32_t base, float4 *stage) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (EGR_WAVE - 1);
     if (ok) {
         stage[4 * lane + 0] = make_float4(u2f(pos), r[0], r[1], r[2]);
         stage[4 * lane + 1] = make_float4(r[3], r[4], r[5], r[6]);
@@ -742,7 +743,7 @@ EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const floa
         stage[4 * lane + 3] = make_float4(r[11], r[12], r[13], r[14]);
     }
     const unsigned long long okm = __ballot(ok);
-    __syncthreads();
+    EGR_BWD_SYNC();
     const float *sf = reinterpret_cast<const float *>(stage);
 #pragma unroll 4
     for (int pass = 0; pass < 16; pass++) {
@@ -752,13 +753,13 @@ EGR_DI void wide_add_wave(const DeviceView &v, bool ok, uint32_t pos, const floa
         const uint32_t p = f2u(sf[16 * src]);
         if (((okm >> src) & 1ull) && c != 0 && x != 0.0f) atomicAdd(v.grad_rows + (size_t)p * EGR_ROW_STRIDE + base + (uint32_t)(c - 1), x);
     }
-    __syncthreads();
+    EGR_BWD_SYNC();
 }
 
 // Flush of the primary step's LDS table: every used slot leaves as two 16-lane records (components 0-14 and 15-21 of the row).
 EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *gt_vals, float4 *stage, int lane) {
     uint32_t sent = 0u; // records (two per used slot)
-    __syncthreads();
+    EGR_BWD_SYNC();
     for (int s0 = 0; s0 < EGR_GT_SLOTS; s0 += EGR_WAVE) { // wave-uniform: wide_add_wave is a wave-level operation
         const int s = min(s0 + lane, EGR_GT_SLOTS - 1); // (a slot count that is no multiple of 64: the lanes beyond the table idle on its last slot)
         const bool in_table = s0 + lane < EGR_GT_SLOTS;
@@ -784,9 +785,94 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
         wide_add_wave(v, valid, pos, hi, 15u, stage);
         sent += 2u * (uint32_t)__popcll(__ballot(valid));
     }
-    __syncthreads();
+    EGR_BWD_SYNC();
     return sent;
 }
+
+// ---- the geometry half of B2 for one hit (backward_pass.cu:151-205): components 0 .. 10 of its gradient (opacity, scale, mean,
+// rotation) from the record position, the ray, the live (.., opacity, sigma) quarter and dL/dalpha. Independent of the other hits of
+// the ray - the sequential half (suffix sums -> dL/dalpha) is the caller's.
+template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float exp_power, const float eps_scale_grad, uint32_t pos, const float4 &a2, const f3 &ro, const f3 &rd, float dL_dalpha, GX &gx) {
+    const float opacity = a2.z, scaling_factor = a2.w;
+    // recompute the local hit exactly as the forward did
+    const float4 W0 = v.inst_w[4 * pos], W1 = v.inst_w[4 * pos + 1], W2 = v.inst_w[4 * pos + 2];
+    f3 lo, ld, dhat, u;
+    float t_unused;
+    bool behind_unused, outside_unused;
+    candidate_geometry(W0, W1, W2, ro, rd, lo, ld, dhat, t_unused, u, behind_unused, outside_unused);
+    const f3 local_hit = u * scaling_factor;
+    const float sq_norm = dot(local_hit, local_hit);
+    const float gaussval = eval_gaussian_sq(sq_norm, exp_power);
+
+    float d_opacity = EGR_MAX_ALPHA * dL_dalpha * gaussval; // :151-152
+    d_opacity = d_opacity * opacity * (1.0f - opacity);
+    const float dL_dgaussval = EGR_MAX_ALPHA * dL_dalpha * opacity; // :155-158
+    const float dL_dsq_norm = gaussval * pow_exp_m1(sq_norm, exp_power);
+    const f3 dL_dx_local = (-local_hit * dL_dsq_norm) * dL_dgaussval;
+    const f3 dL_dx_world = mk3(dot(mk3(W0.x, W1.x, W2.x), dL_dx_local), dot(mk3(W0.y, W1.y, W2.y), dL_dx_local),
+                               dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
+    const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
+    const f3 d_mean = -dL_dx_world;
+    const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3];
+    const f3 scaling = mk3(M0.w, M1.w, M2.w); // exp(scale), stored by k_instances
+    const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
+                       scaling.z * scaling_factor + eps_scale_grad);
+    const f3 rot_0 = mk3(M0.x, M0.y, M0.z) / den, rot_1 = mk3(M1.x, M1.y, M1.z) / den, rot_2 = mk3(M2.x, M2.y, M2.z) / den; // :178-180
+    const f3 d_scale = (dl2w0 * rot_0 + dl2w1 * rot_1 + dl2w2 * rot_2) * scaling; // :181-182
+    const f3 dr0 = dl2w0 * scaling, dr1 = dl2w1 * scaling, dr2 = dl2w2 * scaling; // :185-187
+    const float qn = sqrtf(qu.x * qu.x + qu.y * qu.y + qu.z * qu.z + qu.w * qu.w);
+    const float r = qu.x / qn, x = qu.y / qn, y = qu.z / qn, z = qu.w / qn; // activations.cu:66-69
+    const float dL_dr = 2.f * x * (dr2.y - dr1.z) + 2.f * y * (dr0.z - dr2.x) + 2.f * z * (dr1.x - dr0.y); // :194-205
+    const float dL_dx = -4.f * x * (dr1.y + dr2.z) + 2.f * y * (dr0.y + dr1.x) + 2.f * z * (dr0.z + dr2.x) + 2.f * r * (dr2.y - dr1.z);
+    const float dL_dy = 2.f * x * (dr0.y + dr1.x) - 4.f * y * (dr0.x + dr2.z) + 2.f * z * (dr1.z + dr2.y) + 2.f * r * (dr0.z - dr2.x);
+    const float dL_dz = 2.f * x * (dr0.z + dr2.x) + 2.f * y * (dr1.z + dr2.y) - 4.f * z * (dr0.x + dr1.y) + 2.f * r * (dr1.x - dr0.y);
+    const float dd = dL_dr * qu.x + dL_dx * qu.y + dL_dy * qu.z + dL_dz * qu.w; // activations.cu:71-73
+    const float inv3 = 1.0f / (qn * qn * qn), inv1 = 1.0f / qn;
+
+    // :210-220 flush: into the LDS table when a slot is found within 8 probes, else straight to global
+    const float d_rot0 = dd * -qu.x * inv3 + dL_dr * inv1, d_rot1 = dd * -qu.y * inv3 + dL_dx * inv1;
+    const float d_rot2 = dd * -qu.z * inv3 + dL_dy * inv1, d_rot3 = dd * -qu.w * inv3 + dL_dz * inv1;
+    gx[GC_OPA] = d_opacity, gx[GC_SCALE] = d_scale.x, gx[GC_SCALE + 1] = d_scale.y, gx[GC_SCALE + 2] = d_scale.z;
+    gx[GC_MEAN] = d_mean.x, gx[GC_MEAN + 1] = d_mean.y, gx[GC_MEAN + 2] = d_mean.z;
+    gx[GC_ROT] = d_rot0, gx[GC_ROT + 1] = d_rot1, gx[GC_ROT + 2] = d_rot2, gx[GC_ROT + 3] = d_rot3;
+}
+
+// One batch of 64 hits of a bounce step's queue (backward_task.inc: pass 2), lane = hit: the geometry gradient from the hit's record index, the
+// ray and dL/dalpha, the radiance part from the ray's dL/drgb, all 15 components out as one record. Queue, rays and radiance gradients are the
+// LDS of the wave that OWNS the tile; `stage` is the executing wave's. Returns the records sent.
+EGR_DI uint32_t bounce_batch(const DeviceView &v, const float exp_power, const float eps_scale_grad, const uint4 *bitems, const float *bdl, const float *bray, uint32_t i0, uint32_t nitems,
+                             float4 *stage, int lane) {
+    const bool valid = i0 + (uint32_t)lane < nitems;
+    uint32_t dpos = 0;
+    float gx[15];
+#pragma unroll
+    for (int c = 0; c < 15; c++) gx[c] = 0.0f;
+    if (valid) {
+        // (everything a hit needs beyond its gaussian's records travels in the queue or sits in LDS: the fetches of this pass - live quarter,
+        // W, M - are ONE round trip; it used to re-read the arena row first and the ray from the state)
+        const uint4 item = bitems[i0 + (uint32_t)lane];
+        const uint32_t ray = item.x, pos = item.z;
+        const float weight = u2f(item.w);
+        const float4 a2 = v.inst_w[4 * pos + 3];
+        const f3 iro = mk3(bray[ray], bray[EGR_WAVE + ray], bray[2 * EGR_WAVE + ray]), ird = mk3(bray[3 * EGR_WAVE + ray], bray[4 * EGR_WAVE + ray], bray[5 * EGR_WAVE + ray]);
+        hit_geometry_fn(v, exp_power, eps_scale_grad, pos, a2, iro, ird, u2f(item.y), gx);
+        gx[GC_RGB] = bdl[ray] * weight, gx[GC_RGB + 1] = bdl[EGR_WAVE + ray] * weight, gx[GC_RGB + 2] = bdl[2 * EGR_WAVE + ray] * weight;
+        gx[GC_WEIGHT] = weight;
+        dpos = pos;
+    }
+    wide_add_wave(v, valid, dpos, gx, 0u, stage);
+    return (uint32_t)__popcll(__ballot(valid));
+}
+
+// Teams of the backward chain (under-filled ranks of a partition): per wave a ticket (epoch << 20 | batches << 10 | next batch) for the chunk of
+// bounce hits it has queued, the number of items, and the batches done. No list order is at stake here - gradients are atomic adds.
+#ifndef EGR_BWD_TEAM
+#define EGR_BWD_TEAM 4 // waves per workgroup of the backward chain's team build
+#endif
+template <int TEAM> struct BwdTeamShared {
+    uint32_t done;
+    uint32_t ticket[TEAM], nitems[TEAM], finished[TEAM];
+};
 
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
 // last bounce first (15 gradient components per hit, straight out as wide adds), then the primary step (22 components through
@@ -800,16 +886,50 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
 #ifndef EGR_BWD_WAVES
 #define EGR_BWD_WAVES 3
 #endif
-__global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(EGR_BWD_WAVES, EGR_BWD_WAVES))) k_backward_chain(DeviceView v) {
-    const int lane = threadIdx.x;
-    __shared__ uint32_t gt_keys[EGR_GT_SLOTS];
-    __shared__ __attribute__((aligned(16))) float gt_vals[EGR_GT_STRIDE * EGR_GT_SLOTS];
-    __shared__ uint32_t gt_claim[EGR_GT_SLOTS]; // which lane adds to a slot in this round (backward_task.inc)
-    __shared__ float4 stage[4 * EGR_WAVE]; // records on their way out (wide_add_wave)
+// A team mate without tiles: take batches of the chunks its team mates have open (backward_task.inc: the ticket) until all waves are through.
+template <int TEAM> EGR_DI uint32_t bwd_team_help(const DeviceView &v, const float exp_power, const float eps_scale_grad, BwdTeamShared<TEAM> &bteam, float (*gt_vals_all)[EGR_GT_STRIDE * EGR_GT_SLOTS],
+                                                  float4 *stage, const int wv, const int lane) {
+    uint32_t records = 0u;
+    while (uniform_u32(lds_peek(&bteam.done)) < (uint32_t)TEAM) {
+        bool any = false;
+        for (int dlt = 1; dlt < TEAM; dlt++) {
+            const int w = (wv + dlt) % TEAM;
+            const uint32_t peek = uniform_u32(lds_peek(&bteam.ticket[w]));
+            if ((peek & 0x3FFu) >= ((peek >> 10) & 0x3FFu)) continue; // nothing open there
+            uint32_t tk = 0u;
+            if (lane == 0) tk = atomicAdd(&bteam.ticket[w], 1u); // (epoch, batches and the batch taken come back in ONE word)
+            tk = uniform_u32(tk);
+            const uint32_t bi = tk & 0x3FFu, nbatch = (tk >> 10) & 0x3FFu;
+            if (bi >= nbatch) continue;
+            // the owner does not touch its queue, rays or radiance gradients before `finished` says that every batch of the chunk is done
+            const uint32_t nitems = uniform_u32(lds_peek(&bteam.nitems[w]));
+            const uint4 *bitems = reinterpret_cast<const uint4 *>(gt_vals_all[w]);
+            records += bounce_batch(v, exp_power, eps_scale_grad, bitems, gt_vals_all[w] + 16 * EGR_WAVE, gt_vals_all[w] + 19 * EGR_WAVE, bi * (uint32_t)EGR_WAVE, nitems, stage, lane);
+            if (lane == 0) atomicAdd(&bteam.finished[w], 1u);
+            any = true;
+        }
+        if (!any) __builtin_amdgcn_s_sleep(2);
+    }
+    return records;
+}
+
+template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribute__((amdgpu_waves_per_eu(EGR_BWD_WAVES, EGR_BWD_WAVES))) k_backward_chain(DeviceView v) {
+    const int lane = threadIdx.x & (EGR_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ uint32_t gt_keys_all[TEAM][EGR_GT_SLOTS];
+    __shared__ __attribute__((aligned(16))) float gt_vals_all[TEAM][EGR_GT_STRIDE * EGR_GT_SLOTS];
+    __shared__ uint32_t gt_claim_all[TEAM][EGR_GT_SLOTS]; // which lane adds to a slot in this round (backward_task.inc)
+    __shared__ float4 stage_all[TEAM][4 * EGR_WAVE];     // records on their way out (wide_add_wave)
+    __shared__ BwdTeamShared<TEAM> bteam;
+    uint32_t *const gt_keys = gt_keys_all[wv], *const gt_claim = gt_claim_all[wv];
+    float *const gt_vals = gt_vals_all[wv];
+    float4 *const stage = stage_all[wv];
+    if (threadIdx.x == 0) bteam.done = 0u;
+    if (threadIdx.x < TEAM) bteam.ticket[threadIdx.x] = 0u, bteam.nitems[threadIdx.x] = 0u, bteam.finished[threadIdx.x] = 0u;
+    uint32_t bepoch = 0u;
 #if EGR_BWD_COMPACT
     // the two queues of the bounce steps live in the table's memory: the table is empty (flushed, all zero) while a tile's bounce steps run -
-    // they come before its primary step - and the words they dirtied are cleared again before that step (backward_task.inc). 2.75 KB less
-    // LDS per wave: 94 table slots instead of 64 at the same twelve waves per CU.
+    // they come before its primary step - and the words they dirtied are cleared again before that step (backward_task.inc).
 #define EGR_BQ_FLOATS (25 * EGR_WAVE) // floats of the table's memory the bounce steps use
     static_assert(EGR_GT_STRIDE * EGR_GT_SLOTS >= EGR_BQ_FLOATS, "the bounce queues must fit into the table");
     uint4 *bitems = reinterpret_cast<uint4 *>(gt_vals);  // [4 x 64] bounce steps: (ray, dL/dalpha, record, weight) of the hits of a chunk of four rows
@@ -818,7 +938,7 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
 #endif
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < EGR_GT_STRIDE * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
-    __syncthreads();
+    __syncthreads(); // the kernel's only workgroup barrier (a team's waves run independently from here on)
     const float exp_power = *v.cfg.exp_power;
     const float eps_scale_grad = *v.cfg.eps_scale_grad;
     const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
@@ -842,9 +962,9 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
         }
 #if EGR_BWD_COMPACT
         if (table_dirty) {
-            __syncthreads();
+            EGR_BWD_SYNC();
             for (int s = lane; s < EGR_BQ_FLOATS; s += EGR_WAVE) gt_vals[s] = 0.0f;
-            __syncthreads();
+            EGR_BWD_SYNC();
         }
 #endif
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
@@ -867,6 +987,11 @@ __global__ void __launch_bounds__(EGR_WAVE) __attribute__((amdgpu_waves_per_eu(E
             }
         }
 #endif
+    }
+    if constexpr (TEAM > 1) {
+        // no tiles left: this wave takes batches of bounce hits its team mates have queued until all of them are through
+        if (lane == 0) atomicAdd(&bteam.done, 1u);
+        records += bwd_team_help<TEAM>(v, exp_power, eps_scale_grad, bteam, gt_vals_all, stage, wv, lane);
     }
     if (lane == 0 && records) atomicAdd(v.control + CW_BUCKET_RECORDS, records);
 }
@@ -1064,7 +1189,7 @@ void egr_trace_alloc(egr_context *c) {
     }
     if (getenv("EGR_DEBUG_OCCUPANCY")) {
         int bwd = 0;
-        EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, k_backward_chain, EGR_WAVE, 0));
+        EGR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, k_backward_chain<1>, EGR_WAVE, 0));
         fprintf(stderr, "[egr] resident waves per CU: forward chain %d, backward chain %d\n", per_cu, bwd);
     }
     if (const char *e = getenv("EGR_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // tuning knob
@@ -1160,6 +1285,8 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
         // strands for rank 0 of an 8-way partition, 18.7 / 18.3 / 18.0 ms for the whole image)
         const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : ((uint64_t)(v.num_tasks >> (v.task_shift - 2u)) >= 4ull * c->num_slots ? c->strands : 1); // (counted in 8x8 tiles)
         const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
+        static const int bwd_team_env = getenv("EGR_BWD_TEAM_HELP") ? atoi(getenv("EGR_BWD_TEAM_HELP")) : -1; // (experiments: 0 / 1 force the choice)
+        const bool backward_teams = bwd_team_env >= 0 ? bwd_team_env != 0 : (c->world > 1 && (uint64_t)(v.num_tasks >> (v.task_shift - 2u)) < 2ull * c->num_slots);
         if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
         for (int st = 0; st < S; st++) {
             hipStream_t ls = S > 1 ? c->strand_stream[st] : s;
@@ -1191,7 +1318,10 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
             egr_stamp_end(c, ls);
             if (grads) {
                 egr_stamp_begin(c, "backward_chain", ls);
-                hipLaunchKernelGGL(k_backward_chain, sgrid, block, 0, ls, w);
+                // (under-filled ranks: the backward chain as teams whose waves without tiles take batches of their mates' bounce hits - gradients are
+                // atomic adds, so no result depends on who sends them; a whole image keeps single-wave workgroups: a team's LDS is only released with its last wave)
+                if (backward_teams) hipLaunchKernelGGL(k_backward_chain<EGR_BWD_TEAM>, dim3((sgrid.x + EGR_BWD_TEAM - 1u) / EGR_BWD_TEAM), dim3(EGR_WAVE * EGR_BWD_TEAM), 0, ls, w);
+                else hipLaunchKernelGGL(k_backward_chain<1>, sgrid, block, 0, ls, w);
                 egr_stamp_end(c, ls);
             } else {
                 egr_stamp_begin(c, "write_outputs", ls);
