@@ -1286,7 +1286,7 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
         const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : ((uint64_t)(v.num_tasks >> (v.task_shift - 2u)) >= 4ull * c->num_slots ? c->strands : 1); // (counted in 8x8 tiles)
         const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
         static const int bwd_team_env = getenv("EGR_BWD_TEAM_HELP") ? atoi(getenv("EGR_BWD_TEAM_HELP")) : -1; // (experiments: 0 / 1 force the choice)
-        const bool backward_teams = bwd_team_env >= 0 ? bwd_team_env != 0 : (c->world > 1 && (uint64_t)(v.num_tasks >> (v.task_shift - 2u)) < 2ull * c->num_slots);
+        const bool backward_teams = bwd_team_env >= 0 ? bwd_team_env != 0 : (c->team_help == 1 || (c->world > 1 && (uint64_t)(v.num_tasks >> (v.task_shift - 2u)) < 2ull * c->num_slots)); // (egr_set_team_help(1) takes the teams of both chains: tests/test_hip_parity.py)
         if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
         for (int st = 0; st < S; st++) {
             hipStream_t ls = S > 1 ? c->strand_stream[st] : s;

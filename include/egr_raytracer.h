@@ -200,7 +200,9 @@ int egr_set_rays_per_task(egr_context *ctx, int rays_per_task);
  * tile, for ranks of a multi-GPU partition whose launch lasts as long as their heaviest tile. Help changes the ORDER in which a ray's candidates
  * enter its list, never the set: the per-pixel statistics stay equal, the total transmittance product rounds differently in its last bit and
  * exactly tied depths may composite in another order from run to run (deviation (a)). 0 = off (default: forward outputs are
- * reproducible bit for bit), 1 = on; also env EGR_TEAM_HELP at creation. Returns 1 for other values. */
+ * reproducible bit for bit), 1 = on; also env EGR_TEAM_HELP at creation. Returns 1 for other values. (1 also selects the backward chain's
+ * team build, which an under-filled rank of a partition gets in any case: its waves without tiles take batches of their team mates' bounce
+ * hits - gradients are atomic adds, no result depends on it.) */
 int egr_set_team_help(egr_context *ctx, int on);
 
 /* Synchronises the stream and returns the work counters / status of the most recent egr_raytrace.

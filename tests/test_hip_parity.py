@@ -611,7 +611,9 @@ def test_team_help_changes_the_list_order_only(ren, orc, syn):
     """egr_set_team_help(1): waves without tiles walk (ray, node) pairs their team mates offer (several waves on one heavy tile). The SET of
     candidates of every ray stays what it was - both per-pixel statistics and every counter equal the run without help - only the order in
     which they enter the ray's list may change: the total-transmittance product rounds differently in its last bit, everything else follows
-    from that (a small image leaves most waves of every team without a tile, so help is the rule here, not the exception)."""
+    from that (a small image leaves most waves of every team without a tile, so help is the rule here, not the exception). The switch also
+    takes the BACKWARD chain's team build (a partition's under-filled rank gets it without asking: its waves without tiles take batches of
+    their team mates' bounce hits): the gradients of the runs with help are compared with the run without."""
     W, H = 96, 64
     g = syn.make_scene(4000, "trained", seed=21)
     cam = syn.default_camera()
