@@ -953,23 +953,10 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
         unsigned long long bw_t1 = 0ull;
         uint32_t bw_rows0 = 0u;
 #endif
+        // The steps of a tile are independent in the backward (each reads its own arena chain and the forward's state, all gradients are
+        // atomic adds), so their order is free: the PRIMARY step goes first and the bounce steps last - the bounce steps' batches are what
+        // team mates can take (backward_task.inc), and team mates only have time once their own tiles are through, i.e. late in a heavy tile.
         bool table_dirty = false; // (wave-uniform) a bounce step used the table's memory for its queues
-        for (int step = num_bounces; step >= 1; step--) {
-            constexpr bool PRIMARY = false;
-            do {
-#include "backward_task.inc"
-            } while (false);
-        }
-#if EGR_BWD_COMPACT
-        if (table_dirty) {
-            EGR_BWD_SYNC();
-            for (int s = lane; s < EGR_BQ_FLOATS; s += EGR_WAVE) gt_vals[s] = 0.0f;
-            EGR_BWD_SYNC();
-        }
-#endif
-#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
-        bw_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
         {
             constexpr bool PRIMARY = true;
             const int step = 0;
@@ -977,6 +964,22 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
 #include "backward_task.inc"
             } while (false);
         }
+#if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
+        bw_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        for (int step = num_bounces; step >= 1; step--) {
+            constexpr bool PRIMARY = false;
+            do {
+#include "backward_task.inc"
+            } while (false);
+        }
+#if EGR_BWD_COMPACT
+        if (table_dirty) { // (the table's memory held the bounce steps' queues: empty again for the next tile's primary step)
+            EGR_BWD_SYNC();
+            for (int s = lane; s < EGR_BQ_FLOATS; s += EGR_WAVE) gt_vals[s] = 0.0f;
+            EGR_BWD_SYNC();
+        }
+#endif
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
         {
             const unsigned long long bw_t2 = __builtin_amdgcn_s_memrealtime();

@@ -1,4 +1,4 @@
-"""Diagnostic (EGR_TASK_TIMES=8 build): start / bounce-steps end / end of every task's BACKWARD chain and its number of primary hit rows."""
+"""Diagnostic (EGR_TASK_TIMES=8 build): start / primary-step end / end of every task's BACKWARD chain and its number of primary hit rows."""
 import importlib, sys, os, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 syn = importlib.import_module("editable-gaussian-reflections_amd.synthetic"); ren = importlib.import_module("editable-gaussian-reflections_amd.renderer")
@@ -18,7 +18,7 @@ t0 = tr[::8, 0::8].cpu().numpy().astype(np.int64).ravel(); t2 = ac[::8, 0::8].cp
 t1 = tr[::8, 1::8].cpu().numpy().astype(np.int64).ravel(); rows = ac[::8, 1::8].cpu().numpy().astype(np.int64).ravel()
 own = (t2 > t0) & (t1 >= t0)
 t0, t1, t2, rows = t0[own], t1[own], t2[own], rows[own]
-tot, bounce, prim = (t2 - t0) * 0.01, (t1 - t0) * 0.01, (t2 - t1) * 0.01
+tot, prim, bounce = (t2 - t0) * 0.01, (t1 - t0) * 0.01, (t2 - t1) * 0.01  # (the primary step runs first, the bounce steps last)
 o = np.argsort(-tot)[:10]
 print("tasks", len(tot), "span us", (t2.max() - t0.min()) * 0.01, "sum / 3072 slots", tot.sum() / 3072, "mean task", tot.mean(), "max", tot.max())
 print("heaviest tasks (us: total | bounce steps | primary step | primary hit rows):", [(round(float(tot[i]), 1), round(float(bounce[i]), 1), round(float(prim[i]), 1), int(rows[i])) for i in o])
