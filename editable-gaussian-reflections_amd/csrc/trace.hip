@@ -874,9 +874,9 @@ template <int TEAM> struct BwdTeamShared {
     uint32_t ticket[TEAM], nitems[TEAM], finished[TEAM];
 };
 
-// The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps,
-// last bounce first (15 gradient components per hit, straight out as wide adds), then the primary step (22 components through
-// the LDS table). Per-step code: backward_task.inc.
+// The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps - the
+// primary step (22 gradient components per hit through the LDS table), then the bounce steps, last bounce first (15 components per
+// hit, straight out as wide adds; in the team build their batches can be taken by team mates). Per-step code: backward_task.inc.
 #ifndef EGR_COMBINE_MASK
 #define EGR_COMBINE_MASK 0 // (round 4, with the flushed table: no level beyond lane ^ 1, lane ^ 8 - 2.95-2.97 against 3.01-3.03 ms with lane ^ 2; it was 1) primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
 #endif
