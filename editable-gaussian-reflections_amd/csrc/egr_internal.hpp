@@ -92,6 +92,8 @@ struct DeviceView { // everything a kernel needs, passed by value
     float4 *hit_arena;     // blocks of (1 + EGR_HIT_BLOCK_ROWS) rows x 64 lanes
     uint32_t hit_blocks_cap;
     uint32_t *task_last_block; // [NSTEPS][num_tasks]  last arena block of the task's step (or ~0u)
+    uint32_t *task_cost;       // [num_tasks] grad launches: what the forward chain expects the task's backward to cost (hit rows / hits)
+    uint32_t *bwd_order;       // [num_tasks] the order in which the backward chain takes this rank's tasks: costliest first inside every queue's chunk (k_order_backward)
     float *state;          // internal per-ray state, SoA by task-linear index (see trace.hip)
     uint32_t state_stride; // = padded number of task-linear rays
     uint32_t *control;     // device counters (see ControlWord)
@@ -187,6 +189,7 @@ struct egr_context {
     float4 *hit_arena = nullptr;
     uint32_t hit_blocks_cap = 0;
     uint32_t *task_last_block = nullptr;
+    uint32_t *task_cost = nullptr, *bwd_order = nullptr;
     float *state = nullptr;
     uint32_t state_stride = 0;
     uint32_t num_tasks_total = 0; // 8x8 wave tiles in the whole image (a 16x16 macro tile = 4 of them = 256 rays of ray state)

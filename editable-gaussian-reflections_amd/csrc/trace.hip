@@ -667,6 +667,7 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9 // diagnostic build: stamps of the WHOLE chain of a task (start, end of every step) in its first pixels
         unsigned long long chain_t[EGR_NSTEPS + 1] = {__builtin_amdgcn_s_memrealtime(), 0ull, 0ull, 0ull};
 #endif
+        uint32_t bwd_cost = 0u; // (grad launches) what this tile's backward will cost, roughly in microseconds: 8 per primary hit row, 8 per 64 bounce hits + 2 per bounce hit row
         for (int step = 0; step <= num_bounces; step++) {
             do { // (a `continue` in the step body ends the step)
                 const float near_plane = step == 0 ? *v.cam.znear : 0.0f; // forward_pass.cu:8-11
@@ -674,6 +675,10 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
                 const uint32_t a = wave_sum_u32(active ? 1u : 0u), b = wave_sum_u32(active ? traversed : 0u), c2 = wave_sum_u32(active ? nhits : 0u);
                 const uint32_t d2 = wave_sum_u32(active ? cnt : 0u);
                 if (lane == 0) wc[4 * step] += a, wc[4 * step + 1] += b, wc[4 * step + 2] += c2, wc[4 * step + 3] += d2;
+                if (GRADS) {
+                    const uint32_t rows = wave_max_u32(active ? nhits : 0u);
+                    bwd_cost += step == 0 ? 8u * rows : c2 / 8u + 2u * rows;
+                }
             } while (false);
             // R4 / R5 of this step for the tile's rays
             const uint32_t etask = v.task_begin + tq;
@@ -683,6 +688,7 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
             chain_t[step + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         }
+        if (GRADS && lane == 0) v.task_cost[v.task_begin + tq] = bwd_cost;
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9
         {
             const TaskGeom ctg = task_geom(v, v.task_begin + tq, lane);
@@ -886,6 +892,52 @@ template <int TEAM> struct BwdTeamShared {
 #ifndef EGR_BWD_WAVES
 #define EGR_BWD_WAVES 3
 #endif
+// Between the two chains of a grad launch: the order in which the backward chain takes this strand's tasks. The forward chain knows what a
+// tile's backward will cost (its hit rows and hits), and a persistent-wave kernel ends with a tail as long as the tiles that START LATE and
+// RUN LONG: per-task stamps of the whole image put the backward chain at 2807 us where a longest-first list schedule of the same task times
+// needs 2289 us (dense-init; by this proxy 2323 us). One workgroup per queue chunk (wave_next_task: 8 chunks = compact image blocks, one
+// per XCD) sorts ITS tasks by descending cost (counting sort over 256 buckets) - a chunk's tiles stay on its XCD, only their order changes.
+#ifndef EGR_ORDER_BUCKETS
+#define EGR_ORDER_BUCKETS 16 // cost classes of the backward order
+#endif
+#ifndef EGR_ORDER_SHIFT
+#define EGR_ORDER_SHIFT 7 // a class spans 2^7 = 128 units of cost (~ microseconds)
+#endif
+__global__ void __launch_bounds__(256) k_order_backward(DeviceView v) {
+    // STABLE: inside a cost class the tiles keep the order of the chunk (a Z-curve over a compact image block: neighbours in time touch neighbouring records)
+    __shared__ uint32_t cnt[EGR_ORDER_BUCKETS][256 + 1];
+    const uint32_t chunk = ((v.task_count + 7u) / 8u + 3u) & ~3u, q = blockIdx.x;
+    const uint32_t beg = q * chunk, end = min(beg + chunk, v.task_count);
+    if (beg >= end) return;
+    const uint32_t t = threadIdx.x, n = end - beg, per = (n + 255u) / 256u;
+    const uint32_t i0 = min(t * per, n), i1 = min(i0 + per, n); // thread t owns the contiguous items [i0, i1) of the chunk
+    auto bucket = [](uint32_t cost) { return (uint32_t)EGR_ORDER_BUCKETS - 1u - min(cost >> EGR_ORDER_SHIFT, (uint32_t)EGR_ORDER_BUCKETS - 1u); }; // (descending: costliest first)
+    for (int b = 0; b < EGR_ORDER_BUCKETS; b++) cnt[b][t] = 0u;
+    for (uint32_t i = i0; i < i1; i++) cnt[bucket(v.task_cost[v.task_begin + beg + i])][t]++;
+    __syncthreads();
+    if (t < (uint32_t)EGR_ORDER_BUCKETS) { // exclusive scan over the threads, one cost class per thread
+        uint32_t acc = 0u;
+        for (int j = 0; j < 256; j++) {
+            const uint32_t c = cnt[t][j];
+            cnt[t][j] = acc, acc += c;
+        }
+        cnt[t][256] = acc;
+    }
+    __syncthreads();
+    uint32_t start[EGR_ORDER_BUCKETS]; // where this thread's items of every class go
+    uint32_t acc = 0u;
+#pragma unroll
+    for (int b = 0; b < EGR_ORDER_BUCKETS; b++) start[b] = acc + cnt[b][t], acc += cnt[b][256];
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t bk = bucket(v.task_cost[v.task_begin + beg + i]);
+        uint32_t at = 0u;
+#pragma unroll
+        for (int b = 0; b < EGR_ORDER_BUCKETS; b++)
+            if ((uint32_t)b == bk) at = start[b]++;
+        v.bwd_order[v.task_begin + beg + at] = v.task_begin + beg + i;
+    }
+}
+
 // A team mate without tiles: take batches of the chunks its team mates have open (backward_task.inc: the ticket) until all waves are through.
 template <int TEAM> EGR_DI uint32_t bwd_team_help(const DeviceView &v, const float exp_power, const float eps_scale_grad, BwdTeamShared<TEAM> &bteam, float (*gt_vals_all)[EGR_GT_STRIDE * EGR_GT_SLOTS],
                                                   float4 *stage, const int wv, const int lane) {
@@ -983,7 +1035,7 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
         {
             const unsigned long long bw_t2 = __builtin_amdgcn_s_memrealtime();
-            const TaskGeom btg = task_geom(v, v.task_begin + tq, lane);
+            const TaskGeom btg = task_geom(v, v.bwd_order ? v.bwd_order[v.task_begin + tq] : v.task_begin + tq, lane);
             if (btg.inside) {
                 if (lane == 0) v.stats.num_traversed_per_pixel[btg.pixel_id] = (int32_t)(bw_t0 & 0x7FFFFFFFull), v.stats.num_accumulated_per_pixel[btg.pixel_id] = (int32_t)(bw_t2 & 0x7FFFFFFFull);
                 if (lane == 1) v.stats.num_traversed_per_pixel[btg.pixel_id] = (int32_t)(bw_t1 & 0x7FFFFFFFull), v.stats.num_accumulated_per_pixel[btg.pixel_id] = (int32_t)bw_rows0;
@@ -1165,7 +1217,7 @@ void egr_build_task_order(egr_context *c) {
 void egr_trace_free(egr_context *c) {
     for (auto &o : c->task_orders) egr_dev_free(c, o.table);
     c->task_orders.clear(), c->task_macro = nullptr;
-    egr_dev_free(c, c->stack_spill), egr_dev_free(c, c->cand_keys), egr_dev_free(c, c->cand_vals), egr_dev_free(c, c->hit_arena), egr_dev_free(c, c->task_last_block), egr_dev_free(c, c->state), egr_dev_free(c, c->control), egr_dev_free(c, c->queues), egr_dev_free(c, c->denoise_tmp), egr_dev_free(c, c->ext_keys), egr_dev_free(c, c->ext_vals);
+    egr_dev_free(c, c->stack_spill), egr_dev_free(c, c->cand_keys), egr_dev_free(c, c->cand_vals), egr_dev_free(c, c->hit_arena), egr_dev_free(c, c->task_last_block), egr_dev_free(c, c->task_cost), egr_dev_free(c, c->bwd_order), egr_dev_free(c, c->state), egr_dev_free(c, c->control), egr_dev_free(c, c->queues), egr_dev_free(c, c->denoise_tmp), egr_dev_free(c, c->ext_keys), egr_dev_free(c, c->ext_vals);
     for (int i = 0; i < EGR_MAX_STRANDS; i++) {
         if (c->strand_stream[i]) (void)hipStreamDestroy(c->strand_stream[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -1216,6 +1268,8 @@ void egr_trace_alloc(egr_context *c) {
     c->hit_blocks_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(blocks, 64), 0x7FFFFFFFull);
     egr_dev_alloc_raw(c, (void **)&c->hit_arena, (size_t)c->hit_blocks_cap * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE * sizeof(float4));
     egr_dev_alloc_raw(c, (void **)&c->task_last_block, (size_t)EGR_NSTEPS * 4u * c->num_tasks_total * sizeof(uint32_t)); // (up to 16 tasks per macro tile)
+    egr_dev_alloc_raw(c, (void **)&c->task_cost, (size_t)4u * c->num_tasks_total * sizeof(uint32_t));
+    egr_dev_alloc_raw(c, (void **)&c->bwd_order, (size_t)4u * c->num_tasks_total * sizeof(uint32_t));
     if (const char *e = getenv("EGR_RAYS_PER_TASK")) c->rays_per_task = atoi(e);
     c->state_stride = c->num_tasks_total * EGR_WAVE;
     egr_dev_alloc_raw(c, (void **)&c->state, (size_t)F_TOTAL * c->state_stride * sizeof(float));
@@ -1261,7 +1315,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.ext_keys = c->ext_keys, v.ext_vals = c->ext_vals, v.ext_blocks_cap = c->ext_blocks_cap;
-    v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block;
+    v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block, v.task_cost = c->task_cost, v.bwd_order = c->bwd_order;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.cube_mode = c->exact_stats ? 1 : 0;
     v.grad_overwrite = c->grad_overwrite ? 1 : 0;
@@ -1320,6 +1374,9 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
             else launch_forward(std::integral_constant<int, 1>{});
             egr_stamp_end(c, ls);
             if (grads) {
+                static const bool order_backward = !(getenv("EGR_ORDER_BACKWARD") && atoi(getenv("EGR_ORDER_BACKWARD")) == 0); // (experiments: 0 = tasks in queue order)
+                w.bwd_order = order_backward ? c->bwd_order : nullptr;
+                if (order_backward) hipLaunchKernelGGL(k_order_backward, dim3(8), dim3(256), 0, ls, w);
                 egr_stamp_begin(c, "backward_chain", ls);
                 // (under-filled ranks: the backward chain as teams whose waves without tiles take batches of their mates' bounce hits - gradients are
                 // atomic adds, so no result depends on who sends them; a whole image keeps single-wave workgroups: a team's LDS is only released with its last wave)

@@ -23,3 +23,12 @@ o = np.argsort(-tot)[:10]
 print("tasks", len(tot), "span us", (t2.max() - t0.min()) * 0.01, "sum / 3072 slots", tot.sum() / 3072, "mean task", tot.mean(), "max", tot.max())
 print("heaviest tasks (us: total | bounce steps | primary step | primary hit rows):", [(round(float(tot[i]), 1), round(float(bounce[i]), 1), round(float(prim[i]), 1), int(rows[i])) for i in o])
 print("mean: bounce steps", bounce.mean(), "primary step", prim.mean(), "primary rows", rows.mean(), "us per primary row", prim.sum() / max(rows.sum(), 1))
+# what another ORDER of the same tasks would give (list schedule on the backward chain's wave slots): as started, longest first, and longest
+# first by a proxy the forward chain knows before the backward starts (primary hit rows)
+import heapq
+def sim(order, slots=3072):
+    h = [0.0] * slots; heapq.heapify(h); fin = 0.0
+    for i in order:
+        x = heapq.heappop(h); heapq.heappush(h, x + tot[i]); fin = max(fin, x + tot[i])
+    return fin
+print("list schedule of these task times on 3072 slots: in start order", round(sim(np.argsort(t0)), 1), "| longest first", round(sim(np.argsort(-tot)), 1), "| most primary rows first", round(sim(np.argsort(-rows)), 1), "| sum / slots", round(tot.sum() / 3072, 1))
