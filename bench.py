@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--emulate-rank", type=int, default=0, help="which rank's tiles --emulate-world traces")
     p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
     p.add_argument("--team-help", type=int, default=-1, help="egr_set_team_help: waves without tiles help their team mates' walks (1 / 0); default: on for ranks of a partition (--gpus N > 1, --emulate-world), off for a whole image")
+    p.add_argument("--ppll-forward", type=int, default=400_000_000, help="forward capacity in the reference's 36-B entries (its own test uses 300M at 1536x1024; its default is 180M)")
+    p.add_argument("--ppll-backward", type=int, default=300_000_000, help="backward capacity (reference default 120M)")
     p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
     a = p.parse_args()
     if a.config == "B":
@@ -135,7 +137,7 @@ def main():
         g = syn.make_scene(N, variant, seed=0)
         pc = ren.GaussianParams(g)
         # capacities: same meaning as the reference's ppll sizes (entries of 36 B); its own test uses 300M/200M at 1536x1024
-        rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=400_000_000, ppll_backward_size=300_000_000, rank=rank, world_size=world)
+        rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=a.ppll_forward, ppll_backward_size=a.ppll_backward, rank=rank, world_size=world)
         m = rt.cuda_module
         m.get_config().num_bounces.fill_(a.bounces)
         if a.strands > 0:
