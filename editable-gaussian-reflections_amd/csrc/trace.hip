@@ -795,6 +795,113 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
     return sent;
 }
 
+#ifndef EGR_COMBINE_MASK
+#define EGR_COMBINE_MASK 0 // (round 4, with the flushed table: no level beyond lane ^ 1, lane ^ 8 - 2.95-2.97 against 3.01-3.03 ms with lane ^ 2; it was 1) primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
+#endif
+// The 22 gradient components of the PRIMARY hits of one hit row (one per lane; `pos` = record index) on their way into the wave's LDS table, in two
+// calls: primary_presum (1), then primary_table_add (2, 3), which returns true for a lane whose contribution found no slot and has to leave
+// as two records of its own.
+//  (1) Primary tiles are coherent: the pixel to the right / below very often composites the SAME gaussian at the same hit index, so equal
+//      neighbours are summed in registers first (two DPP levels: x neighbour, then y neighbour) and only the surviving lane touches the table.
+//  (2) The table, keyed by record index. LDS float atomics retire about ONE LANE PER CLOCK PER CU, shared by all resident waves: 22
+//      ds_add_f32 per hit row (1408 lane-operations) made the table half of the backward chain (round 3, per-phase stamps: 12k of 23k
+//      wave-cycles per row on the dense-init cloud). The table is private to this wave, so only lanes of the SAME row can collide, and only
+//      on the same gaussian: a lane finds its slot with plain reads (one CAS when it has to create it), the lanes of a slot elect one of them
+//      per round through a claim word, and the winner adds its 22 components with plain ds_read / ds_write (conflict-free: odd slot stride)
+//      - the others follow in the next round (after the register-level pre-sums few slots see more than one lane).
+//  (3) A hit that finds no slot within 8 probes: the table is (as good as) full. A tile of the dense-init cloud composites more gaussians
+//      (~ 100-130) than the table holds, and every hit of a gaussian without a slot used to leave the wave as two 64-B records of its own -
+//      a resident gaussian costs two per TILE. The hits of a tile arrive far to near, layer by layer, so what a full table holds is mostly
+//      done with: the wave empties it (two records per used slot, counted in `records`) and looks its hits up again.
+// (1): called by the lanes that hold a hit (inside their divergent block: `__ballot(true)` is the set of them); returns whether this lane still owns a contribution.
+EGR_DI bool primary_presum(const uint32_t pos, float (&gx)[EGR_GT_COMPS], const int lane) {
+    bool mine = true;
+    {
+        const unsigned long long em = __ballot(true);
+#define EGR_FETCH_DPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xF, 0xF, false)
+#define EGR_FETCH_SWZ(x, pat) __builtin_amdgcn_ds_swizzle((int)(x), pat) // bit-mask mode: lane ^ xor inside a group of 32 (no LDS memory touched)
+#define EGR_FETCH_X32(x, unused) __shfl_xor((int)(x), 32)
+#define EGR_FETCH_DPP4(x, unused) __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, (int)(x), 0x141, 0xF, 0xF, false), 0x1B, 0xF, 0xF, false)
+#define EGR_COMBINE(d, FETCH, arg)                                                                            \
+    {                                                                                                          \
+        const bool pact = ((em >> ((uint32_t)lane ^ (d))) & 1ull) != 0ull;                                     \
+        const uint32_t ppos = (uint32_t)FETCH(pos, arg), pmine = (uint32_t)FETCH(mine ? 1 : 0, arg);           \
+        const bool same = pact && pmine != 0u && mine && ppos == pos;                                          \
+        const bool take = same && ((uint32_t)lane & (d)) == 0u;                                                \
+        _Pragma("unroll") for (int c = 0; c < EGR_GT_COMPS; c++) {                                             \
+            const float o = __int_as_float(FETCH(__float_as_int(gx[c]), arg));                                 \
+            gx[c] += take ? o : 0.0f;                                                                          \
+        }                                                                                                      \
+        if (same && !take) mine = false;                                                                       \
+    }
+#if !defined(EGR_X1) || EGR_X1 != 1
+        EGR_COMBINE(1u, EGR_FETCH_DPP, 0xB1)  // quad_perm [1,0,3,2]: lane ^ 1
+#endif
+#if !defined(EGR_X1) || EGR_X1 == 0
+        EGR_COMBINE(8u, EGR_FETCH_DPP, 0x128) // row_ror 8: lane ^ 8
+#endif
+#if (EGR_COMBINE_MASK & 1) && (!defined(EGR_X1) || EGR_X1 == 0)
+        EGR_COMBINE(2u, EGR_FETCH_DPP, 0x4E)  // quad_perm [2,3,0,1]: lane ^ 2 (survivors of the first level, two pixels apart)
+#endif
+#if EGR_COMBINE_MASK & 2
+        EGR_COMBINE(4u, EGR_FETCH_DPP4, 0)    // lane ^ 4 = (lane ^ 7) ^ 3: row_half_mirror, then quad_perm [3,2,1,0]
+#endif
+#if EGR_COMBINE_MASK & 4
+        EGR_COMBINE(16u, EGR_FETCH_SWZ, 0x401F) // lane ^ 16: two rows of pixels apart
+#endif
+#if EGR_COMBINE_MASK & 8
+        EGR_COMBINE(32u, EGR_FETCH_X32, 0)      // lane ^ 32
+#endif
+#undef EGR_COMBINE
+#undef EGR_FETCH_DPP
+#undef EGR_FETCH_SWZ
+#undef EGR_FETCH_X32
+#undef EGR_FETCH_DPP4
+    }
+    return mine;
+}
+// (2), (3): wave-level; `want` = this lane holds a contribution (primary_presum) that looks for a table slot.
+EGR_DI bool primary_table_add(const DeviceView &v, const bool want, const uint32_t pos, const float (&gx)[EGR_GT_COMPS], uint32_t *gt_keys, float *gt_vals, uint32_t *gt_claim, float4 *stage,
+                              const int lane, uint32_t &records) {
+    bool found = false;
+    uint32_t slot = 0u;
+    auto probe = [&]() {
+        slot = ((((pos * 2654435761u) >> 16) * (uint32_t)EGR_GT_SLOTS) >> 16); // keyed by record index (multiply-shift: any slot count)
+        found = false;
+#pragma unroll 1
+        for (int pr = 0; pr < ((want && EGR_PRIMARY_TABLE) ? 8 : 0); pr++) {
+            uint32_t key = *reinterpret_cast<volatile uint32_t *>(&gt_keys[slot]);
+            if (key == EGR_GT_EMPTY) key = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, pos), key = key == EGR_GT_EMPTY ? pos : key; // (another lane of this row may have taken it meanwhile)
+            if (key == pos) { found = true; break; }
+            slot = slot + 1u == (uint32_t)EGR_GT_SLOTS ? 0u : slot + 1u;
+        }
+    };
+    probe();
+#if EGR_FLUSH_WHEN_FULL
+    if (__ballot(want && !found) != 0ull) {
+        records += grad_table_flush(v, gt_keys, gt_vals, stage, lane);
+        probe();
+    }
+#endif
+    bool pending = found; // this lane's contribution still has to be added to its table slot
+    while (__ballot(pending) != 0ull) { // the rounds of the table update (wave-uniform loop)
+        if (pending) gt_claim[slot] = (uint32_t)lane;
+        EGR_BWD_SYNC();
+        const bool win = pending && gt_claim[slot] == (uint32_t)lane;
+        if (win) {
+            float *cell = gt_vals + slot * EGR_GT_STRIDE;
+            float cur[EGR_GT_COMPS];
+#pragma unroll
+            for (int c = 0; c < EGR_GT_COMPS; c++) cur[c] = cell[c];
+#pragma unroll
+            for (int c = 0; c < EGR_GT_COMPS; c++) cell[c] = cur[c] + gx[c];
+            pending = false;
+        }
+        EGR_BWD_SYNC();
+    }
+    return want && !found; // (still no slot: the 22 components leave as two 16-lane records, like a flushed slot)
+}
+
 // ---- the geometry half of B2 for one hit (backward_pass.cu:151-205): components 0 .. 10 of its gradient (opacity, scale, mean,
 // rotation) from the record position, the ray, the live (.., opacity, sigma) quarter and dL/dalpha. Independent of the other hits of
 // the ray - the sequential half (suffix sums -> dL/dalpha) is the caller's.
@@ -883,9 +990,6 @@ template <int TEAM> struct BwdTeamShared {
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps - the
 // primary step (22 gradient components per hit through the LDS table), then the bounce steps, last bounce first (15 components per
 // hit, straight out as wide adds; in the team build their batches can be taken by team mates). Per-step code: backward_task.inc.
-#ifndef EGR_COMBINE_MASK
-#define EGR_COMBINE_MASK 0 // (round 4, with the flushed table: no level beyond lane ^ 1, lane ^ 8 - 2.95-2.97 against 3.01-3.03 ms with lane ^ 2; it was 1) primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
-#endif
 #ifndef EGR_BWD_COMPACT
 #define EGR_BWD_COMPACT 1 // bounce-step backward: per-ray suffix sums first, then the per-hit geometry with one lane per HIT (backward_task.inc)
 #endif
