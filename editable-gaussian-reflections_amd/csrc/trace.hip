@@ -996,6 +996,9 @@ template <int TEAM> struct BwdTeamShared {
 #ifndef EGR_BWD_WAVES
 #define EGR_BWD_WAVES 3
 #endif
+#ifndef EGR_HOIST_BOUNCE
+#define EGR_HOIST_BOUNCE 1 // bounce-step backward, pass 1: a chunk's eight fetches issued before its arithmetic (0: each row fetches for itself; backward chain 2.72 -> 2.66 ms trained-like, 2.645 -> 2.61 dense-init)
+#endif
 // Between the two chains of a grad launch: the order in which the backward chain takes this strand's tasks. The forward chain knows what a
 // tile's backward will cost (its hit rows and hits), and a persistent-wave kernel ends with a tail as long as the tiles that START LATE and
 // RUN LONG: per-task stamps of the whole image put the backward chain at 2807 us where a longest-first list schedule of the same task times
