@@ -795,6 +795,9 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
     return sent;
 }
 
+#ifndef EGR_EARLY_M
+#define EGR_EARLY_M 1 // backward, per-hit geometry: the M rows requested together with the W rows
+#endif
 #ifndef EGR_COMBINE_MASK
 #define EGR_COMBINE_MASK 0 // (round 4, with the flushed table: no level beyond lane ^ 1, lane ^ 8 - 2.95-2.97 against 3.01-3.03 ms with lane ^ 2; it was 1) primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
 #endif
@@ -909,6 +912,9 @@ template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float
     const float opacity = a2.z, scaling_factor = a2.w;
     // recompute the local hit exactly as the forward did
     const float4 W0 = v.inst_w[4 * pos], W1 = v.inst_w[4 * pos + 1], W2 = v.inst_w[4 * pos + 2];
+#if EGR_EARLY_M
+    const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3]; // (requested with W: left where they are used, the compiler issues them ~ 500 instructions later and the row waits a second time)
+#endif
     f3 lo, ld, dhat, u;
     float t_unused;
     bool behind_unused, outside_unused;
@@ -926,7 +932,9 @@ template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float
                                dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
     const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
     const f3 d_mean = -dL_dx_world;
+#if !EGR_EARLY_M
     const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3];
+#endif
     const f3 scaling = mk3(M0.w, M1.w, M2.w); // exp(scale), stored by k_instances
     const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
                        scaling.z * scaling_factor + eps_scale_grad);
