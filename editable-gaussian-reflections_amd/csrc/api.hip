@@ -52,7 +52,7 @@ template <class F> int guarded(egr_context *c, F &&f) {
 
 extern "C" {
 
-const char *egr_version(void) { return "egr-hip 0.5 (gfx950)"; } // 0.4: egr_counters grew (round 3), egr_get_counters_ex, egr_set_rays_per_task; 0.5: egr_set_team_help
+const char *egr_version(void) { return "egr-hip 0.6 (gfx950)"; } // 0.6: egr_grad_delta_consumed (round 5); 0.4: egr_counters grew (round 3), egr_get_counters_ex, egr_set_rays_per_task; 0.5: egr_set_team_help
 
 int egr_create(egr_context **out, int device, int width, int height, int64_t ppll_forward_size, int64_t ppll_backward_size) {
     if (!out || width <= 0 || height <= 0) return 1;
@@ -118,6 +118,13 @@ int egr_set_partition(egr_context *c, int rank, int world) {
 int egr_set_grad_overwrite(egr_context *c, int enable) {
     if (!c) return 1;
     c->grad_overwrite = enable != 0;
+    c->delta_pending = false;
+    return 0;
+}
+
+int egr_grad_delta_consumed(egr_context *c) {
+    if (!c) return 1;
+    c->delta_pending = false;
     return 0;
 }
 

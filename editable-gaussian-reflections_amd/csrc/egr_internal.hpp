@@ -170,6 +170,7 @@ struct egr_context {
     float2 *cand_vals = nullptr;
     uint32_t *stack_spill = nullptr;
     bool grad_overwrite = false;  // egr_set_grad_overwrite
+    bool delta_pending = false;   // the per-launch buffer holds a grad launch the caller has not consumed yet (egr_grad_delta_consumed): the next grad launch ADDS
     bool exact_stats = false;     // egr_set_exact_stats: cube boxes + reference-defined candidate count (takes effect at the next update / rebuild)
     bool boxes_are_cubes = false; // what the current tree was refitted with
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final

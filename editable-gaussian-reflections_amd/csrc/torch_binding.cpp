@@ -275,7 +275,7 @@ struct GaussianDataHolder : torch::CustomClassHolder {
             .def_readonly("dL_drotation", &GaussianDataHolder::dL_drotation)
             .def_readonly("total_weight", &GaussianDataHolder::total_weight)
             .def_readonly("grad_flat", &GaussianDataHolder::grad_flat)    // addition: [22N] view of all of the above
-            .def_readonly("grad_delta", &GaussianDataHolder::grad_delta); // addition: per-launch accumulation target (empty unless use_grad_delta)
+            .def_readonly("grad_delta", &GaussianDataHolder::grad_delta); // addition: per-launch gradient buffer (empty unless use_grad_delta): stored by the first grad launch after grad_delta_consumed(), added to by further ones
     }
 };
 
@@ -400,8 +400,9 @@ struct Raytracer : torch::CustomClassHolder {
         gaussian_data->set_use_delta(on);
         egr_gaussians g = gaussian_data->reify();
         check(egr_set_gaussians(ctx, &g), "use_grad_delta");
-        check(egr_set_grad_overwrite(ctx, on ? 1 : 0), "use_grad_delta"); // a grad launch STORES its sums in grad_delta: nobody clears it
+        check(egr_set_grad_overwrite(ctx, on ? 1 : 0), "use_grad_delta"); // the first grad launch after grad_delta_consumed() STORES its sums in grad_delta (nobody clears it), further ones add
     }
+    void grad_delta_consumed() { check(egr_grad_delta_consumed(ctx), "grad_delta_consumed"); } // the caller folded grad_delta into grad_flat: the next grad launch stores again
     // exact statistics: num_traversed_per_pixel / the candidate counters become the reference's intersection-program invocation
     // count (cube boxes, slower). Takes effect with the next update_bvh() / rebuild_bvh(); raytrace() refuses to run in between.
     void set_exact_stats(bool on) { check(egr_set_exact_stats(ctx, on ? 1 : 0), "set_exact_stats"); }
@@ -498,6 +499,7 @@ struct Raytracer : torch::CustomClassHolder {
             // additions for multi-GPU tile partitioning, measurement and tests
             .def("set_partition", &Raytracer::set_partition)
             .def("use_grad_delta", &Raytracer::use_grad_delta)
+            .def("grad_delta_consumed", &Raytracer::grad_delta_consumed)
             .def("set_exact_stats", &Raytracer::set_exact_stats)
             .def("set_strands", &Raytracer::set_strands)
             .def("set_team_help", &Raytracer::set_team_help)

@@ -325,8 +325,9 @@ EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plan
         } else if (!(seg == 0 ? (t >= near_plane && t <= far_plane) : seg == 1 ? (t < near_plane) : (t > far_plane))) return 0;
         // OptiX only invokes the intersection program when the instance's unit cube overlaps [tmin,tmax]. A response point
         // inside the unit sphere AND on the segment (segment 0) is itself a point of cube and segment, so the cube test is
-        // implied for everything segment 0 ACCEPTS; the hits it rejects (behind, outside the sphere) are counted without asking
-        // whether the reference would have looked at them (default launches count evaluated records, egr_set_exact_stats counts
+        // implied for everything segment 0 ACCEPTS; of the hits it rejects, those behind the origin or back-facing are counted without
+        // asking whether the reference would have looked at them, those outside the ellipsoid are not counted at all (default launches
+        // count the candidates INSIDE their ellipsoid - include/egr_raytracer.h, egr_set_exact_stats -, the exact-statistics build counts
         // the reference's invocations). Segments 1 / 2 hold the Q1 hits, accepted only if the cube overlaps [tmin,tmax].
         if constexpr (!SEG0)
             if (seg != 0 && !hits_unit_cube(lo, ld, near_plane, far_plane)) return 0;
@@ -837,13 +838,9 @@ EGR_DI bool primary_presum(const uint32_t pos, float (&gx)[EGR_GT_COMPS], const 
         }                                                                                                      \
         if (same && !take) mine = false;                                                                       \
     }
-#if !defined(EGR_X1) || EGR_X1 != 1
         EGR_COMBINE(1u, EGR_FETCH_DPP, 0xB1)  // quad_perm [1,0,3,2]: lane ^ 1
-#endif
-#if !defined(EGR_X1) || EGR_X1 == 0
         EGR_COMBINE(8u, EGR_FETCH_DPP, 0x128) // row_ror 8: lane ^ 8
-#endif
-#if (EGR_COMBINE_MASK & 1) && (!defined(EGR_X1) || EGR_X1 == 0)
+#if EGR_COMBINE_MASK & 1
         EGR_COMBINE(2u, EGR_FETCH_DPP, 0x4E)  // quad_perm [2,3,0,1]: lane ^ 2 (survivors of the first level, two pixels apart)
 #endif
 #if EGR_COMBINE_MASK & 2
@@ -1011,7 +1008,7 @@ template <int TEAM> struct BwdTeamShared {
 // tile's backward will cost (its hit rows and hits), and a persistent-wave kernel ends with a tail as long as the tiles that START LATE and
 // RUN LONG: per-task stamps of the whole image put the backward chain at 2807 us where a longest-first list schedule of the same task times
 // needs 2289 us (dense-init; by this proxy 2323 us). One workgroup per queue chunk (wave_next_task: 8 chunks = compact image blocks, one
-// per XCD) sorts ITS tasks by descending cost (counting sort over 256 buckets) - a chunk's tiles stay on its XCD, only their order changes.
+// per XCD) sorts ITS tasks by descending cost (stable counting sort over EGR_ORDER_BUCKETS = 16 cost classes) - a chunk's tiles stay on its XCD, only their order changes.
 #ifndef EGR_ORDER_BUCKETS
 #define EGR_ORDER_BUCKETS 16 // cost classes of the backward order
 #endif
@@ -1285,9 +1282,30 @@ uint32_t egr_num_tasks_for_rank(const egr_context *c) {
 // block index keeps a rank from sitting at the same place of every block (two ranks: a checkerboard, not columns). The plain
 // `tile index % world` of rounds 1-3 gave every rank vertical 16-pixel column stripes whenever the number of tile columns was a
 // multiple of the world size (120 at 1920 px: 2, 4, 8).
-// Mirrors: parallel.tile_owner (Python), Oracle::owner_of_tile (the CPU checker).
+// Mirrors: parallel.tile_owner (Python), Oracle::set_partition (the CPU checker, oracle/egr_oracle.cpp); exported to C hosts as egr_tile_owner.
 // Order of this rank's macro tiles: sort by (XCD chunk block, Z-curve inside the block). The 8 chunks that
 // wave_next_task hands to the 8 XCD queues are equal slices of this order, so each is a compact image block.
+static std::vector<std::pair<uint32_t, uint32_t>> egr_macro_tile_zorder(uint32_t mtx, uint32_t mty) { // (Z-curve key, macro tile) of the whole image, sorted
+    auto part1by1 = [](uint32_t x) {
+        x &= 0xFFFFu;
+        x = (x | (x << 8)) & 0x00FF00FFu, x = (x | (x << 4)) & 0x0F0F0F0Fu, x = (x | (x << 2)) & 0x33333333u, x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> zorder;
+    zorder.reserve((size_t)mtx * mty);
+    for (uint32_t m = 0; m < mtx * mty; m++) zorder.push_back({part1by1(m % mtx) | (part1by1(m / mtx) << 1), m});
+    std::sort(zorder.begin(), zorder.end());
+    return zorder;
+}
+extern "C" int egr_tile_owner(int width, int height, int world, int tile_index) {
+    if (width <= 0 || height <= 0 || world < 1) return -1;
+    const uint32_t mtx = ((uint32_t)width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = ((uint32_t)height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
+    if (tile_index < 0 || (uint32_t)tile_index >= mtx * mty) return -1;
+    const auto zorder = egr_macro_tile_zorder(mtx, mty);
+    for (size_t i = 0; i < zorder.size(); i++)
+        if (zorder[i].second == (uint32_t)tile_index) return (int)((i + i / (size_t)world) % (size_t)world);
+    return -1;
+}
 void egr_build_task_order(egr_context *c) {
     for (const auto &o : c->task_orders)
         if (o.rank == c->rank && o.world == c->world) { // built before: kernels in flight keep reading the table they were launched with
@@ -1300,15 +1318,7 @@ void egr_build_task_order(egr_context *c) {
         c->task_orders.clear();
     }
     const uint32_t mtx = (c->width + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE, mty = (c->height + EGR_MACRO_TILE - 1) / EGR_MACRO_TILE;
-    auto part1by1 = [](uint32_t x) {
-        x &= 0xFFFFu;
-        x = (x | (x << 8)) & 0x00FF00FFu, x = (x | (x << 4)) & 0x0F0F0F0Fu, x = (x | (x << 2)) & 0x33333333u, x = (x | (x << 1)) & 0x55555555u;
-        return x;
-    };
-    std::vector<std::pair<uint32_t, uint32_t>> zorder; // (Z-curve key, macro tile) of the whole image
-    zorder.reserve((size_t)mtx * mty);
-    for (uint32_t m = 0; m < mtx * mty; m++) zorder.push_back({part1by1(m % mtx) | (part1by1(m / mtx) << 1), m});
-    std::sort(zorder.begin(), zorder.end());
+    const std::vector<std::pair<uint32_t, uint32_t>> zorder = egr_macro_tile_zorder(mtx, mty);
     std::vector<std::pair<uint64_t, uint32_t>> keyed;
     for (size_t b = 0; b * (size_t)c->world < zorder.size(); b++) { // this rank's share: one tile of every block of `world` Z-order positions
         const size_t i = b * (size_t)c->world + (size_t)(((uint32_t)c->rank + (uint32_t)c->world - (uint32_t)(b % (size_t)c->world)) % (uint32_t)c->world);
@@ -1433,7 +1443,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block, v.task_cost = c->task_cost, v.bwd_order = c->bwd_order;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.cube_mode = c->exact_stats ? 1 : 0;
-    v.grad_overwrite = c->grad_overwrite ? 1 : 0;
+    v.grad_overwrite = (c->grad_overwrite && !c->delta_pending) ? 1 : 0;
     return v;
 }
 
@@ -1511,9 +1521,12 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
     }
     if (grads && v.n && (v.num_tasks || c->grad_overwrite)) { // (a rank without tiles still owes its per-launch buffer a row of zeros)
         egr_stamp_begin(c, "backward_grad_gather", s);
-        if (c->grad_overwrite) hipLaunchKernelGGL(k_grad_gather<true>, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
+        // (per-launch buffer: the FIRST grad launch after the caller consumed the buffer stores, any further one before the next
+        // egr_grad_delta_consumed adds - two launches before a fold never drop the first one's gradients)
+        if (v.grad_overwrite) hipLaunchKernelGGL(k_grad_gather<true>, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
         else hipLaunchKernelGGL(k_grad_gather<false>, dim3((v.n + 255u) / 256u), dim3(256), 0, s, v);
         egr_stamp_end(c, s);
+        if (c->grad_overwrite) c->delta_pending = true;
     }
     hipLaunchKernelGGL(k_epilogue, dim3(1), dim3(64), 0, s, v, grads ? 1 : 0);
 }

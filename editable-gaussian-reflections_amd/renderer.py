@@ -79,8 +79,17 @@ class GaussianRaytracer:
     OUTPUT_BUFFERS = ("output_rgb", "output_depth", "output_normal", "output_f0", "output_roughness", "output_transmittance",
                       "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final")
 
+    EVAL_MODES = ("gather", "full_image")
+
     def __init__(self, pc, image_width: int, image_height: int, ppll_forward_size=None, ppll_backward_size=None, rank=0, world_size=1,
-                 gather_buffers=None, team_help=False):
+                 gather_buffers=None, team_help=False, eval_mode="gather", group=None):
+        """`eval_mode` (partitioned tracers only; also a per-call argument): what a no-grad render does.
+        "gather": every rank traces its own tiles and the images are completed with ONE all-gather - a COLLECTIVE: every rank of
+        `group` must make the call (needs a process group whose size equals `world_size`; without one the rank traces the whole image).
+        "full_image": this rank traces the whole image itself, no collective - for the usual `if rank == 0: evaluate()` pattern.
+        `group`: the process group of the partition's ranks (None = the default group); used by the gradient all-reduce and the gather."""
+        assert eval_mode in self.EVAL_MODES, eval_mode
+        self.eval_mode, self.group = eval_mode, group
         self.image_width, self.image_height = image_width, image_height
         # partitioned evaluation renders: which framebuffer outputs `gather_outputs` completes on every rank (default: all ten) and
         # whether every no-grad call does it (False: the caller gathers when it needs the images, e.g. once after the 128 accumulated
@@ -103,7 +112,7 @@ class GaussianRaytracer:
             self.cuda_module.set_team_help(True)
         if world_size > 1:
             self.cuda_module.set_partition(rank, world_size)
-            self.cuda_module.use_grad_delta(True)  # launches accumulate into a per-launch buffer: see all_reduce_grads
+            self.cuda_module.use_grad_delta(True)  # grad launches write a per-launch buffer (the first after a fold stores, further ones add): see all_reduce_grads
         config = self.cuda_module.get_config()  # gaussian_raytracer.py:16-25
         config.loss_weight_diffuse.fill_(pc.cfg.loss_weight_diffuse)
         config.loss_weight_specular.fill_(pc.cfg.loss_weight_specular)
@@ -147,21 +156,25 @@ class GaussianRaytracer:
 
     @torch.no_grad()
     def all_reduce_grads(self):
-        """Multi-GPU exchange step: the launch accumulated this rank's gradients + weights into the zeroed
-        per-launch buffer `grad_delta` ([22N], 88 MB at N=1M; the launch stores, nobody clears it); ONE all-reduce sums it over
-        the ranks, then it is added to the persistent `grad_flat` (whose total_weight tail lives across a whole pruning
-        interval). No-op when the tracer is not partitioned."""
+        """Multi-GPU exchange step: the grad launches since the last fold left this rank's gradients + weights in the
+        per-launch buffer `grad_delta` ([22N], 88 MB at N=1M; the first launch after a fold stores, further ones add, nobody clears it);
+        ONE all-reduce sums it over the ranks, then it is added to the persistent `grad_flat` (whose total_weight tail lives across a
+        whole pruning interval) and the library is told that the buffer is consumed. A collective: every rank of the group calls it.
+        No-op when the tracer is not partitioned."""
         g = self.cuda_module.get_gaussians()
         if g.grad_delta.numel():
-            all_reduce_launch_delta(g.grad_flat, g.grad_delta)
+            all_reduce_launch_delta(g.grad_flat, g.grad_delta, self.group)
+            self.cuda_module.grad_delta_consumed()
 
-    def _partitioned_eval(self):
-        """Evaluation (no-grad) renders of a partitioned tracer: with a process group every rank traces its own tiles and the images are
-        all-gathered (`gather_outputs`); without one (a single process driving one "rank" of a partition, as tools and tests do) there
-        is nobody to gather from, and the rank traces the whole image itself."""
+    def _partitioned_eval(self, eval_mode=None):
+        """Evaluation (no-grad) renders of a partitioned tracer in "gather" mode: with a process group of the partition's size every rank
+        traces its own tiles and the images are all-gathered (`gather_outputs`). In "full_image" mode, or without such a group (a single
+        process driving one "rank" of a partition, as tools and tests do), the rank traces the whole image itself."""
         import torch.distributed as dist
 
-        return self.world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world_size
+        if (eval_mode or self.eval_mode) != "gather":
+            return False
+        return self.world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) == self.world_size
 
     def _set_full_image(self, full):
         """Whole-image no-grad render on a partitioned tracer (no process group, see _partitioned_eval). The library caches the tile
@@ -173,13 +186,13 @@ class GaussianRaytracer:
     def gather_outputs(self, names=None):
         """Completes the framebuffer outputs `names` (default: self.gather_buffers) of the last partitioned no-grad render on every rank:
         one all-gather of each rank's own pixels, bit-identical to a whole-image render. The per-pixel statistics and
-        random_seeds stay per rank. No-op for an unpartitioned tracer."""
+        random_seeds stay per rank. A collective over `self.group`. No-op for an unpartitioned tracer and for one in "full_image" mode."""
         if not self._partitioned_eval():
             return
         fb = self.cuda_module.get_framebuffer()
         if self._image_gather is None:
             self._image_gather = ImageGather(self.image_width, self.image_height, self.rank, self.world_size, fb.output_rgb.device)
-        self._image_gather.gather([getattr(fb, n) for n in (names or self.gather_buffers)])
+        self._image_gather.gather([getattr(fb, n) for n in (names or self.gather_buffers)], self.group)
 
     @staticmethod
     def blender_rotation(R):
@@ -189,7 +202,8 @@ class GaussianRaytracer:
         return Rb
 
     def __call__(self, viewpoint_camera, target=None, target_diffuse=None, target_specular=None, target_depth=None, target_normal=None,
-                 target_roughness=None, target_f0=None, force_update_bvh=False, denoise=False, znear=0.01, zfar=999.9):
+                 target_roughness=None, target_f0=None, force_update_bvh=False, denoise=False, znear=0.01, zfar=999.9, eval_mode=None):
+        assert eval_mode is None or eval_mode in self.EVAL_MODES, eval_mode
         with torch.no_grad():
             R = torch.from_numpy(viewpoint_camera.R).cuda().float() if isinstance(viewpoint_camera.R, np.ndarray) else viewpoint_camera.R.cuda()
             R_c2w_blender = self.blender_rotation(R.clone())
@@ -211,7 +225,7 @@ class GaussianRaytracer:
         if grads or force_update_bvh:
             # raytrace() follows with the same parameter values: one pass over the cloud writes the snapshot AND the live records
             self.cuda_module.update_bvh(True)
-        gathered = not grads and self._partitioned_eval()
+        gathered = not grads and self._partitioned_eval(eval_mode)  # (a collective follows: every rank of the group makes this call - or pass eval_mode="full_image")
         if not grads and not gathered:
             self._set_full_image(True)
         try:
@@ -230,7 +244,7 @@ class GaussianRaytracer:
         return {"render": framebuffer.output_rgb.clone()}
 
 
-def render(camera, raytracer: GaussianRaytracer, targets_available=True, force_update_bvh=False, denoise=False, znear=0.01, zfar=999.9):
+def render(camera, raytracer: GaussianRaytracer, targets_available=True, force_update_bvh=False, denoise=False, znear=0.01, zfar=999.9, eval_mode=None):
     """gaussian_renderer.py:21-92: returns CHW clones rgb[3,3,H,W], final[1,3,H,W], depth/normal/roughness/f0."""
     do_backprop = torch.is_grad_enabled()
     names = ("original_image", "diffuse_image", "specular_image", "normal_image", "f0_image", "roughness_image", "depth_image")
@@ -238,7 +252,7 @@ def render(camera, raytracer: GaussianRaytracer, targets_available=True, force_u
     with torch.set_grad_enabled(do_backprop):
         raytracer(camera, target=tg["original_image"], target_diffuse=tg["diffuse_image"], target_specular=tg["specular_image"],
                   target_depth=tg["depth_image"], target_normal=tg["normal_image"], target_roughness=tg["roughness_image"],
-                  target_f0=tg["f0_image"], force_update_bvh=force_update_bvh, denoise=denoise, znear=znear, zfar=zfar)
+                  target_f0=tg["f0_image"], force_update_bvh=force_update_bvh, denoise=denoise, znear=znear, zfar=zfar, eval_mode=eval_mode)
     fb = raytracer.cuda_module.get_framebuffer()
     cl = lambda t: t.clone().detach().moveaxis(-1, 1)
     return SimpleNamespace(rgb=cl(fb.output_rgb), final=cl(fb.output_denoised) if denoise else cl(fb.output_final), depth=cl(fb.output_depth),

@@ -160,16 +160,27 @@ int egr_raytrace(egr_context *ctx, int grads_enabled, void *hip_stream);
  * the same inputs and output (csrc/denoise.hip; parity with OptiX is unpinned). Env EGR_DENOISE=0 at creation: plain copy. */
 int egr_denoise(egr_context *ctx, void *hip_stream);
 
-/* Multi-GPU image partition (not in the reference): this context only traces the 16x16-pixel
- * macro tiles with (tile_index % world_size) == rank; default rank 0 of 1 = whole image. */
+/* Multi-GPU image partition (not in the reference): this context only traces the 16x16-pixel macro tiles it owns;
+ * default rank 0 of 1 = whole image. Ownership: the macro tiles (index m = my * ceil(width / 16) + mx) are sorted along a Z-curve over
+ * (mx, my); the tile at position i of that order belongs to rank (i + i / world_size) % world_size - every run of world_size
+ * consecutive positions (a compact 2-D block of the image) holds each rank once, rotated by the block index. Hosts that need the map
+ * (image gathers, pixel masks) ask egr_tile_owner instead of re-implementing it. */
 int egr_set_partition(egr_context *ctx, int rank, int world_size);
+/* The rank that owns macro tile `tile_index` (= my * ceil(width / 16) + mx) of a width x height image cut `world_size` ways; -1 for
+ * arguments out of range. Pure host function (no context, no device). */
+int egr_tile_owner(int width, int height, int world_size, int tile_index);
 
 /* Per-launch gradient buffers (not in the reference; the multi-GPU exchange step). The reference's launch ADDS to the
  * gradient tensors (atomicAdd, backward_pass.cu:210-220) and so does this library by default. With enable != 0 the dL_d* / total_weight
- * pointers of egr_set_gaussians are taken as a PER-LAUNCH buffer: every grad launch STORES this launch's sums there (rows no ray
- * touched read 0), so the caller can all-reduce the buffer over the ranks and add it to its persistent gradients without clearing it
- * in between (one write pass over [22N] instead of a read-modify-write, and no memset per iteration). */
+ * pointers of egr_set_gaussians are taken as a PER-LAUNCH buffer: the first grad launch after the caller has consumed the buffer
+ * (egr_grad_delta_consumed; also right after this call) STORES its sums there (rows no ray touched read 0), so the caller can all-reduce
+ * the buffer over the ranks and add it to its persistent gradients without clearing it in between (one write pass over [22N] instead of
+ * a read-modify-write, and no memset per iteration). A grad launch that finds the buffer NOT consumed yet - two launches before one
+ * fold: multi-view accumulation, a caller that raised between launch and fold - ADDS to it like the default path, so no launch's
+ * gradients or total_weight are ever dropped. */
 int egr_set_grad_overwrite(egr_context *ctx, int enable);
+/* The caller has folded the per-launch buffer into its persistent gradients (after the all-reduce): the next grad launch stores again. */
+int egr_grad_delta_consumed(egr_context *ctx);
 
 /* Exact statistics (not in the reference). By default the tree bounds each Gaussian's ELLIPSOID and the walk only has to find the
  * instances whose response point can be accepted, so stats.num_traversed_per_pixel and egr_counters.candidates count the candidates

@@ -573,6 +573,40 @@ def test_tile_partition_sums_to_full_image(ren, orc, syn, monkeypatch, rays_per_
         assert np.abs(s - gfull[k]).max() / (np.abs(gfull[k]).max() + 1e-30) < 1e-3, k
 
 
+def test_per_launch_gradient_buffer_never_drops_a_launch(ren, orc, syn):
+    """use_grad_delta (egr_set_grad_overwrite): the first grad launch after a fold STORES into the per-launch buffer (stale content is
+    overwritten, nobody clears it), a second launch before the fold ADDS (multi-view accumulation, a caller that raised between launch and
+    fold), and grad_delta_consumed() makes the next launch store again."""
+    W, H = 64, 48
+    g = syn.make_scene(2000, "trained", seed=12)
+    cam, tg = syn.default_camera(), syn.make_targets(W, H)
+    rt, _ = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0))
+    m = rt.cuda_module
+    run_grad(ren, rt, cam_obj(ren, cam, tg))
+    one = m.get_gaussians().grad_flat.clone()
+    assert float(one.abs().max()) > 0
+    m.use_grad_delta(True)
+    gd = m.get_gaussians()
+    camera = cam_obj(ren, cam, tg)
+
+    def launch():  # the launch alone (no fold): what a direct cuda_module user does
+        m.get_metadata().total_num_calls.zero_()
+        m.update_bvh(True)
+        m.raytrace()
+        torch.cuda.synchronize()
+
+    rt(camera)  # sets pose, targets, parameters; its own launch is folded into grad_flat and consumed (all_reduce_grads)
+    gd.grad_delta.fill_(123.0)
+    scale = float(one.abs().max())
+    launch()
+    assert float((gd.grad_delta - one).abs().max()) / scale < 1e-5  # stored: the 123s are gone
+    launch()
+    assert float((gd.grad_delta - 2 * one).abs().max()) / scale < 1e-5  # a second launch before the fold adds
+    m.grad_delta_consumed()
+    launch()
+    assert float((gd.grad_delta - one).abs().max()) / scale < 1e-5  # consumed: stores again
+
+
 def test_strands_do_not_change_results(ren, orc, syn):
     """The image slices traced on separate HIP streams (egr_set_strands) are independent: the images are bit-identical
     with 1 or 2 strands, the gradients agree to float-atomic reordering."""

@@ -34,6 +34,21 @@ def test_c_abi_library_exports_every_declared_symbol(libs):
     assert "Tensor" not in hdr and "std::" not in hdr and "hipStream_t" not in hdr
 
 
+def test_c_abi_tile_owner_matches_the_python_mirror(libs):
+    """egr_tile_owner (a pure host function of the C ABI: the Z-curve deal of egr_set_partition) against parallel.tile_owner."""
+    hip_lib, _ = libs
+    par = importlib.import_module(PKG + ".parallel")
+    L = ctypes.CDLL(hip_lib)
+    L.egr_tile_owner.argtypes = [ctypes.c_int] * 4
+    L.egr_tile_owner.restype = ctypes.c_int
+    for (w, h, world) in ((1920, 1080, 8), (1920, 1080, 2), (100, 60, 3), (33, 17, 5), (16, 16, 1)):
+        own = par.tile_owner(w, h, world).reshape(-1)
+        got = np.array([L.egr_tile_owner(w, h, world, i) for i in range(own.size)])
+        assert np.array_equal(got, own), (w, h, world)
+        assert L.egr_tile_owner(w, h, world, own.size) == -1 and L.egr_tile_owner(w, h, world, -1) == -1
+    assert L.egr_tile_owner(0, 10, 2, 0) == -1 and L.egr_tile_owner(10, 10, 0, 0) == -1
+
+
 def test_hip_code_object_targets_gfx950_only(libs):
     hip_lib, _ = libs
     out = subprocess.run(["strings", "-a", hip_lib], stdout=subprocess.PIPE, text=True).stdout
