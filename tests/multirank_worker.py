@@ -71,6 +71,16 @@ same_images("one sample")
 rays = torch.tensor([float(part.cuda_module.get_counters()[0])], dtype=torch.float64)
 dist.all_reduce(rays)
 assert int(rays.item()) == W * H and part.cuda_module.get_counters()[0] < W * H  # nobody traced the whole image
+# the usual `if rank == 0: evaluate()` pattern: eval_mode="full_image" is NOT a collective - rank 0 alone traces the whole image (rank 1 makes no call)
+if rank == 0:
+    with torch.no_grad():
+        for rt in (part, full):
+            rt.cuda_module.get_metadata().total_num_calls.zero_()
+        part(camera, eval_mode="full_image")
+        full(camera)
+    same_images("rank 0 alone, full_image")
+    assert part.cuda_module.get_counters()[0] == W * H
+dist.barrier()
 # render.py:195-209: accumulated samples (jitter on), the gather deferred to the end of the loop, then the denoiser on the whole image
 for rt in (part, full):
     rt.cuda_module.get_config().jitter_primary_rays.fill_(True)
