@@ -44,7 +44,7 @@ inline int nblk(uint64_t n, int bs = BS) { return (int)((n + bs - 1) / bs); }
 // over the cloud (the records' lines are being written here anyway).
 __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, egr_config cfg, const uint32_t *__restrict__ pos_of_gid,
                                                   float4 *__restrict__ inst_w, float4 *__restrict__ inst_m, float *__restrict__ aabb, int cube,
-                                                  float4 *__restrict__ app, int live) {
+                                                  float4 *__restrict__ app, int live, float4 *__restrict__ bsph) {
     uint32_t i = blockIdx.x * BS + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = pos_of_gid ? pos_of_gid[i] : i;
@@ -91,6 +91,14 @@ __global__ void __launch_bounds__(BS) k_instances(uint32_t n, egr_gaussians g, e
         inst_w[4 * slot + a] = usable ? Wr[a] : make_float4(0.f, 0.f, 0.f, 2.f); // 64-B record: rows 0-2 = W, row 3 = live quarter (k_live)
         aabb[6 * i + a] = usable ? lo[a] : 3.0e38f;
         aabb[6 * i + 3 + a] = usable ? hi[a] : -3.0e38f;
+    }
+    {
+        // bounding SPHERE of what the box bounds (centre, squared radius; record order): the ellipsoid's largest semi-axis, in exact-statistics mode
+        // the cube's half diagonal. Primary tiles test it per ray before a (ray, gaussian) pair is evaluated at all (forward_task.inc); padded like the
+        // box, the ray-dependent part of the slack is added there. An unusable gaussian has a radius no ray meets.
+        float rad = cube ? sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : fmaxf(s[0], fmaxf(s[1], s[2]));
+        rad = rad * 1.0001f + 4e-7f * (fabsf(m[0]) + fabsf(m[1]) + fabsf(m[2]) + rad);
+        bsph[slot] = usable && isfinite(rad) ? make_float4(m[0], m[1], m[2], rad * rad) : make_float4(0.f, 0.f, 0.f, -3.0e38f);
     }
     if (live) { // the same expressions as k_live (utils/helpers.cu:10-33)
         app[2 * (size_t)slot] = make_float4(relu_act(g.rgb[3 * i]), relu_act(g.rgb[3 * i + 1]), relu_act(g.rgb[3 * i + 2]), g.normal[3 * i]);
@@ -437,7 +445,7 @@ template <class T> static void dalloc(egr_context *c, T *&p, size_t count) {
 }
 
 void egr_bvh_free(egr_context *c) {
-    egr_dev_free(c, c->wnodes), egr_dev_free(c, c->pos_of_gid), egr_dev_free(c, c->inst_w), egr_dev_free(c, c->inst_m), egr_dev_free(c, c->app), egr_dev_free(c, c->aabb), egr_dev_free(c, c->grad_rows);
+    egr_dev_free(c, c->wnodes), egr_dev_free(c, c->pos_of_gid), egr_dev_free(c, c->inst_w), egr_dev_free(c, c->inst_m), egr_dev_free(c, c->bsph), egr_dev_free(c, c->app), egr_dev_free(c, c->aabb), egr_dev_free(c, c->grad_rows);
     egr_dev_free(c, c->sort_tmp), egr_dev_free(c, c->keys_in), egr_dev_free(c, c->keys_out), egr_dev_free(c, c->vals_in), egr_dev_free(c, c->vals_out);
     egr_dev_free(c, c->k_left), egr_dev_free(c, c->k_right), egr_dev_free(c, c->k_parent), egr_dev_free(c, c->k_first), egr_dev_free(c, c->k_last), egr_dev_free(c, c->k_dp), egr_dev_free(c, c->k_flags), egr_dev_free(c, c->wide_of), egr_dev_free(c, c->scratch_u32), egr_dev_free(c, c->out_of_frame);
     c->n_alloc = 0;
@@ -452,6 +460,7 @@ void egr_bvh_reserve(egr_context *c, uint32_t n) {
     dalloc(c, c->pos_of_gid, cap);
     dalloc(c, c->inst_w, 4 * (size_t)cap);
     dalloc(c, c->inst_m, 4 * (size_t)cap);
+    dalloc(c, c->bsph, (size_t)cap);
     dalloc(c, c->grad_rows, 32 * (size_t)cap);
     EGR_HIP(hipMemset(c->grad_rows, 0, 32 * (size_t)cap * sizeof(float)));
     dalloc(c, c->app, 3 * (size_t)cap);
@@ -502,7 +511,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
         c->bvh_valid = true;
         return;
     }
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0, c->app, 0); // boxes for the frame
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)nullptr, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0, c->app, 0, c->bsph); // boxes for the frame
     uint32_t *bounds = c->scratch_u32, *counters = c->scratch_u32 + 16;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, bounds);
     hipLaunchKernelGGL(k_bounds, dim3(nblk(n)), dim3(BS), 0, s, n, c->aabb, bounds);
@@ -525,7 +534,7 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     size_t bytes = c->sort_tmp_bytes;
     EGR_HIP(rocprim::radix_sort_pairs(c->sort_tmp, bytes, c->keys_in, c->keys_out, c->vals_in, c->vals_out, (size_t)n, 0, 63, s));
     hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(n)), dim3(BS), 0, s, n, c->vals_out, c->pos_of_gid);
-    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0, c->app, 0); // records in leaf order
+    hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0, c->app, 0, c->bsph); // records in leaf order
     if (n == 1) { // a single leaf under a one-child root
         uint4 root[EGR_WIDTH];
         for (int k = 0; k < EGR_WIDTH; k++) root[k] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, k == 0 ? (EGR_LEAF_FLAG | 0u) : EGR_EMPTY_SLOT);
@@ -576,7 +585,7 @@ void egr_bvh_refit(egr_context *c, hipStream_t s, bool fuse_live) {
     c->boxes_are_cubes = c->exact_stats;
     if (n == 0) return;
     hipLaunchKernelGGL(k_instances, dim3(nblk(n)), dim3(BS), 0, s, n, c->g, c->cfg, (const uint32_t *)c->pos_of_gid, c->inst_w, c->inst_m, c->aabb, c->exact_stats ? 1 : 0,
-                       c->app, fuse_live ? 1 : 0);
+                       c->app, fuse_live ? 1 : 0, c->bsph);
     c->live_fresh = fuse_live;
     refit_boxes(c, s);
 }

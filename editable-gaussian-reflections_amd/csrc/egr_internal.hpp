@@ -42,6 +42,7 @@ inline void egr_hip_check(hipError_t e, const char *what) {
 //                       reads them from the parameter tensors), so between an update and the next grad launch the record mixes
 //                       snapshot M rows with the scale / rotation of the last grad launch
 // grad_rows: float[32N] gradient accumulation, one 128-B line per gaussian (22 components used), zero between launches
+// bsph   : float4[N]    bounding sphere of the ellipsoid (centre xyz, squared radius): 16 B, snapshot like W
 // app    : float4[2N]   live per-launch record: (relu rgb, n.x) (n.y, n.z, f0.x, f0.y)       32 B
 // wnodes : uint4[8*Nw]     8-wide BVH, one 128-B line per node; child slot (16 B):
 //          x = lo.x | lo.y<<16, y = lo.z | hi.x<<16, z = hi.y | hi.z<<16 (16-bit cells of the build frame), w = link
@@ -78,6 +79,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     float4 *inst_m;             // [n][4] backward record: rows 0-2 = (M row (snapshot), exp(scale_a) (live)), row 3 = raw quaternion (live)
     float *grad_rows;           // [n][32] gradient accumulation rows in record order (one 128-B line per gaussian)
     float4 *app;                // [n][2] live appearance (k_live writes it per launch)
+    const float4 *bsph;         // [n] bounding sphere of the gaussian's ellipsoid (centre, squared radius; snapshot): the per-ray pre-test of primary tiles
     // per-launch scratch
     float *cand_keys;      // [slots][cand_cap][64]
     float2 *cand_vals;     // [slots][cand_cap][64]  (alpha, gaussian id bits)
@@ -150,7 +152,7 @@ struct egr_context {
     std::vector<uint32_t> level_start;    // host: wide-node index range of each level of the wide tree
     uint32_t *pos_of_gid = nullptr; // gid_of_pos is vals_out (kept after the build)
     BvhFrame frame{0.f, 0.f, 0.f, 1.f, 1.f, 1.f};
-    float4 *inst_w = nullptr, *inst_m = nullptr, *app = nullptr;
+    float4 *inst_w = nullptr, *inst_m = nullptr, *app = nullptr, *bsph = nullptr;
     float *aabb = nullptr;             // [n][6] instance boxes (lo, hi)
     uint32_t *out_of_frame = nullptr;  // device flag written by the refit
     float *grad_rows = nullptr;        // [n_alloc][32] zero between launches (k_grad_gather empties what it reads)

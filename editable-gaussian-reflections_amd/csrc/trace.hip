@@ -48,6 +48,9 @@
 #ifndef EGR_PAIR_PRIMARY
 #define EGR_PAIR_PRIMARY 0 // 1: primary rays walk pairwise too (0: one packet per tile)
 #endif
+#ifndef EGR_LEAF_FILTER
+#define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
+#endif
 #ifndef EGR_PSTK
 #define EGR_PSTK 512 // pair-stack entries kept in LDS
 #endif
@@ -346,6 +349,57 @@ EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plan
     return 2;
 }
 
+// One evaluation batch worked off: lane = one (ray, gaussian) pair whose 64-B record (w0..w2 = rows of W, w3 = live quarter) has arrived. The candidate
+// test, then an accepted candidate takes a slot of its ray's list through the ray's LDS counter (the run in the wave's scratch, beyond cand_cap ONE
+// extension block per ray). Shared by the pair walk of bounce tiles and by the primary tiles' leaf evaluation (forward_task.inc).
+template <bool CUBE, bool SEG0>
+EGR_DI void pair_eval_append(const DeviceView &v, const FwdConst &fc, WalkShared &rays, const size_t scratch0, const int step, const int seg, const float near_plane, const bool have,
+                             const uint32_t er, const uint32_t pidx, const float4 &w0, const float4 &w1, const float4 &w2, const float4 &w3, bool &g_over, WalkStats &st) {
+    const int lane = threadIdx.x & (EGR_WAVE - 1);
+    (void)lane;
+    int res = 0;
+    float t = 0.0f, alpha = 0.0f;
+    if (have) {
+        const float4 q0 = rays.rayp[er][0], q1 = rays.rayp[er][1];
+        res = test_candidate<CUBE, SEG0>(fc, step, seg, near_plane, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), pidx, w0, w1, w2, w3, t, alpha);
+    }
+#ifdef EGR_WALK_STATS
+    st.leafhits += have ? 1u : 0u;
+    st.outer += (lane == 0);
+#endif
+    if (res == 1 || res == 2) atomicAdd(&rays.gtrav[er], 1u);
+    uint32_t at = 0u;
+    if (res == 2) at = atomicAdd(&rays.gcnt[er], 1u);
+    const bool in_ext = res == 2 && at >= v.cand_cap;
+    if (res == 2 && !in_ext) {
+        const size_t slot = (scratch0 + er) * v.cand_cap + at;
+        v.cand_keys[slot] = t, v.cand_vals[slot] = make_float2(alpha, u2f(pidx));
+    }
+    if (__ballot(in_ext) != 0ull) { // rare: some list outgrew its run - it continues in ONE extension block per ray
+        for (;;) { // rays that need a block and have none, one after the other (wave-uniform loop)
+            const unsigned long long pend = __ballot(in_ext && lds_peek(&rays.gext[er]) == EGR_EXT_NONE);
+            if (pend == 0ull) break;
+            const int src = __ffsll((long long)pend) - 1;
+            if (lane == src && atomicCAS(&rays.gext[er], EGR_EXT_NONE, EGR_EXT_LOCKED) == EGR_EXT_NONE) { // (a team mate working on the same ray may be faster)
+                const uint32_t e = atomicAdd(v.control + CW_EXT_BUMP, 1u);
+                lds_poke(&rays.gext[er], e < v.ext_blocks_cap ? e : EGR_EXT_NONE - 1u); // EGR_EXT_NONE - 1 = none left
+            }
+            wave_sync();
+        }
+        if (in_ext) {
+            uint32_t e = lds_peek(&rays.gext[er]);
+            while (e == EGR_EXT_LOCKED) __builtin_amdgcn_s_sleep(1), e = lds_peek(&rays.gext[er]);
+            const uint32_t k = at - v.cand_cap;
+            if (e < EGR_EXT_NONE - 1u && k < EGR_EXT_BLOCK) {
+                v.ext_keys[(size_t)e * EGR_EXT_BLOCK + k] = t;
+                v.ext_vals[(size_t)e * EGR_EXT_BLOCK + k] = make_float2(alpha, u2f(pidx));
+            } else {
+                g_over = true;
+            }
+        }
+    }
+}
+
 // ---- pair walk. Work items are PAIRS, not rays: a wave-wide LIFO of (ray, node) pairs and a buffer of (ray, leaf) pairs,
 // both in LDS. A walk iteration pops up to 8 x EGR_GPOP pairs; lane m of group g tests child slot m of the g-th popped node
 // (one 16-B load per lane = the node's 128-B line per group), hits are compacted with wave-wide ballots: inner children
@@ -437,49 +491,7 @@ EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine,
         }
         wave_sync(); // the reads of both buffers above come before the pushes below
         // ---------------- work off: evaluation batch
-        if (do_eval) {
-            int res = 0;
-            float t = 0.0f, alpha = 0.0f;
-            if (have) {
-                const float4 q0 = rays.rayp[er][0], q1 = rays.rayp[er][1];
-                res = test_candidate<CUBE, SEG0>(fc, step, seg, near_plane, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), pidx, w0, w1, w2, w3, t, alpha);
-            }
-#ifdef EGR_WALK_STATS
-            st.leafhits += have ? 1u : 0u;
-            st.outer += (lane == 0);
-#endif
-            if (res == 1 || res == 2) atomicAdd(&rays.gtrav[er], 1u);
-            uint32_t at = 0u;
-            if (res == 2) at = atomicAdd(&rays.gcnt[er], 1u);
-            const bool in_ext = res == 2 && at >= v.cand_cap;
-            if (res == 2 && !in_ext) {
-                const size_t slot = (scratch0 + er) * v.cand_cap + at;
-                v.cand_keys[slot] = t, v.cand_vals[slot] = make_float2(alpha, u2f(pidx));
-            }
-            if (__ballot(in_ext) != 0ull) { // rare: some list outgrew its run - it continues in ONE extension block per ray
-                for (;;) { // rays that need a block and have none, one after the other (wave-uniform loop)
-                    const unsigned long long pend = __ballot(in_ext && lds_peek(&rays.gext[er]) == EGR_EXT_NONE);
-                    if (pend == 0ull) break;
-                    const int src = __ffsll((long long)pend) - 1;
-                    if (lane == src && atomicCAS(&rays.gext[er], EGR_EXT_NONE, EGR_EXT_LOCKED) == EGR_EXT_NONE) { // (a team mate working on the same ray may be faster)
-                        const uint32_t e = atomicAdd(v.control + CW_EXT_BUMP, 1u);
-                        lds_poke(&rays.gext[er], e < v.ext_blocks_cap ? e : EGR_EXT_NONE - 1u); // EGR_EXT_NONE - 1 = none left
-                    }
-                    wave_sync();
-                }
-                if (in_ext) {
-                    uint32_t e = lds_peek(&rays.gext[er]);
-                    while (e == EGR_EXT_LOCKED) __builtin_amdgcn_s_sleep(1), e = lds_peek(&rays.gext[er]);
-                    const uint32_t k = at - v.cand_cap;
-                    if (e < EGR_EXT_NONE - 1u && k < EGR_EXT_BLOCK) {
-                        v.ext_keys[(size_t)e * EGR_EXT_BLOCK + k] = t;
-                        v.ext_vals[(size_t)e * EGR_EXT_BLOCK + k] = make_float2(alpha, u2f(pidx));
-                    } else {
-                        g_over = true;
-                    }
-                }
-            }
-        }
+        if (do_eval) pair_eval_append<CUBE, SEG0>(v, fc, rays, scratch0, step, seg, near_plane, have, er, pidx, w0, w1, w2, w3, g_over, st);
         // ---------------- work off: walk batch
         if (npop != 0u) {
 #pragma unroll
@@ -599,7 +611,7 @@ template <bool CUBE, int TEAM, class F> EGR_DI void team_help_while(const Device
 __global__ void k_prologue(DeviceView v, int grads) {
     int t = threadIdx.x;
     if (t < CW_RESET_END) v.control[t] = 0;
-    if (t >= CW_DBG && t < CW_COUNT) v.control[t] = 0;
+    for (int w = CW_DBG + t; w < CW_COUNT; w += (int)blockDim.x) v.control[w] = 0; // (diagnostic words: per launch)
     if (t < 16) v.control[CW_DBG2 + t] = 0;
     for (uint32_t q = t; q < EGR_QUEUE_WORDS * v.num_strands; q += blockDim.x) v.queues[q] = 0;
     if (t < 12) v.control[CW_DBG3 + t] = ((t & 3) < 2) ? 0xFFFFFFFFu : 0u;
@@ -668,6 +680,10 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9 // diagnostic build: stamps of the WHOLE chain of a task (start, end of every step) in its first pixels
         unsigned long long chain_t[EGR_NSTEPS + 1] = {__builtin_amdgcn_s_memrealtime(), 0ull, 0ull, 0ull};
 #endif
+#ifdef EGR_TRAVERSAL_STATS
+        const unsigned long long tchain0 = __builtin_amdgcn_s_memtime();
+        unsigned long long tepi = 0ull;
+#endif
         uint32_t bwd_cost = 0u; // (grad launches) what this tile's backward will cost, roughly in microseconds: 8 per primary hit row, 8 per 64 bounce hits + 2 per bounce hit row
         for (int step = 0; step <= num_bounces; step++) {
             do { // (a `continue` in the step body ends the step)
@@ -684,12 +700,24 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
             // R4 / R5 of this step for the tile's rays
             const uint32_t etask = v.task_begin + tq;
             const TaskGeom etg = task_geom(v, etask, lane);
+#ifdef EGR_TRAVERSAL_STATS
+            const unsigned long long tepi0 = __builtin_amdgcn_s_memtime();
+#endif
             if (etg.inside) step_epilogue_lane(v, step, GRADS, num_bounces, etg, state_of(v, etask, lane));
+#ifdef EGR_TRAVERSAL_STATS
+            tepi += __builtin_amdgcn_s_memtime() - tepi0;
+#endif
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9
             chain_t[step + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
         }
         if (GRADS && lane == 0) v.task_cost[v.task_begin + tq] = bwd_cost;
+#ifdef EGR_TRAVERSAL_STATS
+        if (lane == 0) { // CW_DBG2 + 8: step epilogues, + 12: whole chains (task pull to task end)
+            atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 8), tepi);
+            atomicAdd(reinterpret_cast<unsigned long long *>(v.control + CW_DBG2 + 12), __builtin_amdgcn_s_memtime() - tchain0);
+        }
+#endif
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9
         {
             const TaskGeom ctg = task_geom(v, v.task_begin + tq, lane);
@@ -1437,7 +1465,7 @@ DeviceView egr_make_view(const egr_context *c) {
     // (help changes the ORDER in which a ray's candidates enter its list, never the set: off unless the caller asks - egr_set_team_help)
     v.team_help = EGR_TEAM > 1 && c->team_help == 1 ? 1 : 0;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
-    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app;
+    v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app, v.bsph = c->bsph;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
     v.ext_keys = c->ext_keys, v.ext_vals = c->ext_vals, v.ext_blocks_cap = c->ext_blocks_cap;
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block, v.task_cost = c->task_cost, v.bwd_order = c->bwd_order;
