@@ -253,6 +253,7 @@ int egr_get_counters_ex(egr_context *c, void *out_raw, size_t out_bytes, void *s
                         (unsigned long long)u64(CW_DBG2 + 20 + 10 * k), (unsigned long long)u64(CW_DBG2 + 22 + 10 * k), (unsigned long long)u64(CW_DBG2 + 24 + 10 * k));
             fprintf(stderr, "[egr stats forward chain] wave-cycles(s_memtime) whole chains (task pull to end) %llu, of which step epilogues %llu\n", (unsigned long long)u64(CW_DBG2 + 12), (unsigned long long)u64(CW_DBG2 + 8));
             fprintf(stderr, "[egr stats primary composite] wave-cycles(s_memtime) selection scans %llu, arena block %llu, (alpha, record) fetch %llu, pass 1 %llu, appearance pass %llu\n", (unsigned long long)u64(CW_DBG2 + 40), (unsigned long long)u64(CW_DBG2 + 42), (unsigned long long)u64(CW_DBG2 + 44), (unsigned long long)u64(CW_DBG2 + 46), (unsigned long long)u64(CW_DBG2 + 48));
+            fprintf(stderr, "[egr stats primary lists] tiles by their longest candidate list: <=16: %u, <=24: %u, <=32: %u, <=40: %u, <=48: %u, <=64: %u, longer: %u\n", w[CW_DBG2 + 50], w[CW_DBG2 + 51], w[CW_DBG2 + 52], w[CW_DBG2 + 53], w[CW_DBG2 + 54], w[CW_DBG2 + 55], w[CW_DBG2 + 56]);
             fprintf(stderr, "[egr stats primary leaf filter] leaves before the sphere / pyramid test %llu, wave-cycles in the test %llu\n", (unsigned long long)u64(CW_DBG2 + 38), (unsigned long long)u64(CW_DBG2 + 36));
             for (int k = 0; k < 2; k++)
                 fprintf(stderr, "[egr stats %s] wave-cycles(s_memtime) traversal %llu composite %llu | of the traversal: leaf evaluation (frustum walk) %llu (slot +8: %llu)\n", k ? "bounce" : "primary",
