@@ -327,6 +327,12 @@ int egr_debug_get_instances(egr_context *c, float *M, float *W, float *aabb, voi
     });
 }
 
+int egr_debug_set_pixel_mask(egr_context *c, const uint8_t *device_mask) {
+    if (!c) return 1;
+    c->pixel_mask = device_mask;
+    return 0;
+}
+
 int egr_debug_get_step_hits(egr_context *c, int32_t *host_out, void *stream) {
     if (!c || !host_out || require_ready(c, false)) return 1;
     return guarded(c, [&] { egr_export_step_hits(c, host_out, (hipStream_t)stream); });

@@ -104,6 +104,7 @@ struct DeviceView { // everything a kernel needs, passed by value
     uint32_t num_strands;
     int grad_overwrite;    // k_grad_gather stores this launch's sums (per-launch buffer, egr_set_grad_overwrite) instead of adding them
     int team_help;         // forward chain: waves without tiles (or waiting for their own helpers) walk pairs their team mates offer (trace.hip: teams)
+    const uint8_t *pixel_mask; // debug (egr_debug_set_pixel_mask): [H*W], a pixel with mask 0 is treated like a pixel outside the image; null = every pixel
     int cube_mode;         // exact-statistics launch (egr_set_exact_stats): the tree bounds instance CUBES, every overlap is counted
 };
 
@@ -173,6 +174,7 @@ struct egr_context {
     uint32_t *stack_spill = nullptr;
     bool grad_overwrite = false;  // egr_set_grad_overwrite
     bool delta_pending = false;   // the per-launch buffer holds a grad launch the caller has not consumed yet (egr_grad_delta_consumed): the next grad launch ADDS
+    const uint8_t *pixel_mask = nullptr; // egr_debug_set_pixel_mask (caller-owned device memory)
     bool exact_stats = false;     // egr_set_exact_stats: cube boxes + reference-defined candidate count (takes effect at the next update / rebuild)
     bool boxes_are_cubes = false; // what the current tree was refitted with
     int denoise_mode = 1;         // 1: a-trous stand-in (denoise.hip), 0: copy output_final

@@ -50,6 +50,7 @@ EGR_DI TaskGeom task_geom(const DeviceView &v, uint32_t task, int lane) {
     }
     g.inside = (uint32_t)lane < v.rays_per_task && g.px < v.width && g.py < v.height;
     g.pixel_id = (uint32_t)g.py * (uint32_t)v.width + (uint32_t)g.px;
+    if (v.pixel_mask != nullptr && g.inside) g.inside = v.pixel_mask[g.pixel_id] != 0; // (parity tests: trace a chosen set of pixels; wave-uniform branch)
     return g;
 }
 // ray state of (task, lane): task-linear, rays_per_task entries per task (lanes beyond that own no ray and must not touch it)

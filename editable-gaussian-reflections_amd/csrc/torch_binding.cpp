@@ -348,6 +348,7 @@ struct Raytracer : torch::CustomClassHolder {
     c10::intrusive_ptr<StatsDataHolder> stats_data;
     c10::intrusive_ptr<PPLLDataHolder> ppll_forward_data, ppll_backward_data;
     egr_context *ctx = nullptr;
+    Tensor pixel_mask; // debug_set_pixel_mask: the mask the context points at
 
     void check(int rc, const char *what) {
         if (rc != 0) throw std::runtime_error(std::string(what) + ": " + (ctx ? egr_last_error(ctx) : "no context"));
@@ -406,6 +407,17 @@ struct Raytracer : torch::CustomClassHolder {
     // exact statistics: num_traversed_per_pixel / the candidate counters become the reference's intersection-program invocation
     // count (cube boxes, slower). Takes effect with the next update_bvh() / rebuild_bvh(); raytrace() refuses to run in between.
     void set_exact_stats(bool on) { check(egr_set_exact_stats(ctx, on ? 1 : 0), "set_exact_stats"); }
+    // debug: trace only the pixels with mask != 0 ([H*W] or [H, W] uint8 CUDA tensor; an empty tensor clears the mask). The tensor is kept alive here.
+    void debug_set_pixel_mask(Tensor mask) {
+        if (mask.numel() == 0) {
+            pixel_mask = Tensor();
+            check(egr_debug_set_pixel_mask(ctx, nullptr), "debug_set_pixel_mask");
+            return;
+        }
+        TORCH_CHECK(mask.is_cuda() && mask.scalar_type() == torch::kUInt8 && mask.numel() == width * height, "debug_set_pixel_mask: uint8 CUDA tensor with H*W elements expected");
+        pixel_mask = mask.contiguous();
+        check(egr_debug_set_pixel_mask(ctx, pixel_mask.data_ptr<uint8_t>()), "debug_set_pixel_mask");
+    }
     void set_rays_per_task(int64_t n) { TORCH_CHECK(egr_set_rays_per_task(ctx, (int)n) == 0, "set_rays_per_task: 0 (automatic), 16, 32 or 64 expected"); }
     void set_team_help(bool on) { TORCH_CHECK(egr_set_team_help(ctx, on ? 1 : 0) == 0, "set_team_help failed"); }
     void set_strands(int64_t n) { TORCH_CHECK(egr_set_strands(ctx, (int)n) == 0, "set_strands: 1..EGR_STRANDS (value at creation) expected"); }
@@ -500,6 +512,7 @@ struct Raytracer : torch::CustomClassHolder {
             .def("set_partition", &Raytracer::set_partition)
             .def("use_grad_delta", &Raytracer::use_grad_delta)
             .def("grad_delta_consumed", &Raytracer::grad_delta_consumed)
+            .def("debug_set_pixel_mask", &Raytracer::debug_set_pixel_mask)
             .def("set_exact_stats", &Raytracer::set_exact_stats)
             .def("set_strands", &Raytracer::set_strands)
             .def("set_team_help", &Raytracer::set_team_help)

@@ -1471,6 +1471,7 @@ DeviceView egr_make_view(const egr_context *c) {
     v.hit_arena = c->hit_arena, v.hit_blocks_cap = c->hit_blocks_cap, v.task_last_block = c->task_last_block, v.task_cost = c->task_cost, v.bwd_order = c->bwd_order;
     v.state = c->state, v.state_stride = c->state_stride, v.control = c->control;
     v.cube_mode = c->exact_stats ? 1 : 0;
+    v.pixel_mask = c->pixel_mask;
     v.grad_overwrite = (c->grad_overwrite && !c->delta_pending) ? 1 : 0;
     return v;
 }

@@ -240,6 +240,11 @@ int egr_debug_get_instances(egr_context *ctx, float *M, float *W, float *aabb, v
  * int32 [EGR_NUM_STEPS][H*W], host pointer; pixels outside this context's partition read 0. Parity tests use it to LIST the
  * pixels whose bounce rays met a different number of hits than the CPU oracle's. Synchronises. */
 int egr_debug_get_step_hits(egr_context *ctx, int32_t *host_out, void *hip_stream);
+/* Pixel mask for parity tests: device_mask = uint8 [H*W] in DEVICE memory (caller-owned, must outlive the launches that use it), or NULL
+ * to clear. A pixel whose mask byte is 0 is treated like a pixel outside the image by every kernel of a launch: no ray, no outputs written,
+ * no statistics, no gradient contribution. The CPU oracle has the same hook (orc_set_pixel_mask), so both sides can trace exactly the pixels
+ * whose per-step hit counts agree (tests/test_hip_configs.py: the at-size gradient check). Takes effect at the next egr_raytrace. */
+int egr_debug_set_pixel_mask(egr_context *ctx, const uint8_t *device_mask);
 /* BVH self-check: every leaf box equals its instance box, every internal box is the union of its children,
  * every visible instance is reachable exactly once. Returns 0 if consistent. Host-side; synchronises. */
 int egr_debug_check_bvh(egr_context *ctx, void *hip_stream);

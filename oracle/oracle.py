@@ -61,8 +61,11 @@ _OUT_GRAD = ["dL_drgb", "dL_dnormal", "dL_df0", "dL_droughness", "dL_dopacity", 
              "total_weight"]
 
 
+_OUT_DIAG = ["num_bounce_near_ties", "decision_margin"]  # (after num_depth_ties in the C struct)
+
+
 class _Outputs(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_void_p) for k in _OUT_F64 + _OUT_INT + _OUT_GRAD]
+    _fields_ = [(k, ctypes.c_void_p) for k in _OUT_F64 + _OUT_INT + _OUT_DIAG + _OUT_GRAD]
 
 
 def lib():
@@ -219,6 +222,8 @@ class Oracle:
             out[k] = np.zeros((H, W), np.int32)
         out["num_composited_per_step"] = np.zeros((NSTEPS, H, W), np.int32)
         out["num_depth_ties"] = np.zeros((H, W), np.int32)
+        out["num_bounce_near_ties"] = np.zeros((H, W), np.int32)
+        out["decision_margin"] = np.full((H, W), 1e30, np.float64)
         n = self.n
         gshape = {"dL_drgb": (n, 3), "dL_dnormal": (n, 3), "dL_df0": (n, 3), "dL_droughness": (n, 1), "dL_dopacity": (n, 1),
                   "dL_dscale": (n, 3), "dL_dmean": (n, 3), "dL_drotation": (n, 4), "total_weight": (n, 1)}
@@ -242,7 +247,7 @@ class Oracle:
                     keep.append(a)
                     setattr(tg, k, a.ctypes.data)
         o = _Outputs()
-        for k in _OUT_F64 + _OUT_INT + _OUT_GRAD:
+        for k in _OUT_F64 + _OUT_INT + _OUT_DIAG + _OUT_GRAD:
             if k in out:
                 setattr(o, k, out[k].ctypes.data)
         self.L.orc_raytrace(self.h, int(bool(grads_enabled)), ctypes.c_uint32(self.total_num_calls), ctypes.byref(tg), ctypes.byref(o))
