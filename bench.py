@@ -27,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r4"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
+ROUND = "r5"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
 
 
 def parse():
@@ -50,7 +50,7 @@ def parse():
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
     p.add_argument("--emulate-rank", type=int, default=0, help="which rank's tiles --emulate-world traces")
     p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
-    p.add_argument("--team-help", type=int, default=-1, help="egr_set_team_help: waves without tiles help their team mates' walks (1 / 0); default: on for ranks of a partition (--gpus N > 1, --emulate-world), off for a whole image")
+    p.add_argument("--team-help", type=int, default=0, help="egr_set_team_help: waves without tiles help their team mates' walks (1 / 0). Default 0 = the product's default (forward outputs reproducible bit for bit); 1 shortens the forward chain of an under-filled rank by 7-14 % (tools/emu_all.sh measures both)")
     p.add_argument("--ppll-forward", type=int, default=400_000_000, help="forward capacity in the reference's 36-B entries (its own test uses 300M at 1536x1024; its default is 180M)")
     p.add_argument("--ppll-backward", type=int, default=300_000_000, help="backward capacity (reference default 120M)")
     p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
@@ -145,8 +145,7 @@ def main():
         if a.emulate_world > 1:
             assert world == 1
             m.set_partition(a.emulate_rank, a.emulate_world)
-        team_help = a.team_help == 1 or (a.team_help < 0 and (world > 1 or a.emulate_world > 1))
-        m.set_team_help(team_help)
+        m.set_team_help(a.team_help == 1)
 
         def one_step():
             if a.forward_only:
@@ -266,7 +265,7 @@ def main():
             # as profiles/<round>/pmc_summary.json, keyed by workload. bench.py cannot run the profiler around itself.
             pmc, pmc_round = {}, ROUND
             try:
-                pmc_round = next((r for r in (ROUND, "r3") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_summary.json"))), ROUND)  # (this round's passes once they are committed; the traffic source names the round)
+                pmc_round = next((r for r in (ROUND, "r4") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_summary.json"))), ROUND)  # (this round's passes once they are committed; the traffic source names the round)
                 pj = os.path.join(ROOT, "profiles", pmc_round, "pmc_summary.json")
                 if os.path.exists(pj) and world == 1 and a.emulate_world <= 1 and N == (100_000 if a.config == "B" else 1_000_000) and (W, H) == (1920, 1080):
                     pmc = json.load(open(pj)).get(f"{a.config}_{variant}", {})
@@ -300,6 +299,31 @@ def main():
                          "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2),
                          "other_kernels": [roof_of(k) for k in cands if k != dom and k in kern]})
             res["device_bytes"] = int(cc[14])
+        # what a rank's iteration is made of (ranks of a partition, real or emulated): the two chains shrink with the rank's share of the image, the
+        # exchange step is the all-reduce + fold of the [22N] buffer (timed alone, HIP events, every rank takes part), everything else - refit, live
+        # records, gradient gather, the caller's copies, launch gaps - is replicated on every rank
+        if with_profile and a.profile_steps > 0 and (world > 1 or a.emulate_world > 1):
+            ar_ms = None
+            if world > 1:
+                par = importlib.import_module("editable-gaussian-reflections_amd.parallel")
+                gg = m.get_gaussians()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(3):
+                    par.all_reduce_launch_delta(gg.grad_flat, gg.grad_delta)
+                barrier()
+                e0.record()
+                for _ in range(10):
+                    par.all_reduce_launch_delta(gg.grad_flat, gg.grad_delta)
+                e1.record()
+                torch.cuda.synchronize()
+                ar_ms = e0.elapsed_time(e1) / 10.0
+                rt.zero_grad()
+            if rank == 0:
+                chains = float(np.median(acc.get("forward_chain", [0.0]))) + float(np.median(acc.get("backward_chain", [0.0])))
+                res["multi_gpu"] = {"iteration_ms": round(res["ms_per_step"], 4), "chains_ms": round(chains, 4), "allreduce_ms": None if ar_ms is None else round(ar_ms, 4),
+                                    "replicated_ms": round(res["ms_per_step"] - chains - (ar_ms or 0.0), 4),
+                                    "note": "chains = forward + backward chain of this rank's tiles (profile pass, one strand); allreduce = all-reduce + fold of the launch's [22N] fp32 buffer, timed alone; "
+                                            "replicated = the rest of the iteration: refit + live records + gradient gather + the caller's copies + launch gaps, the same on every rank"}
         res["roofline"], res["kernel_ms"] = roof, {k: round(v, 4) for k, v in kern.items()}
         del rt, pc
         torch.cuda.empty_cache()
@@ -324,10 +348,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {a.config}: synthetic dense-init room+spheres cloud, HEADLINE variant = {a.variant} ({label[a.variant]}; "
                                    f"the other variant is in `other_variant`), N={N}, {W}x{H}, {what}, num_bounces={a.bounces}, jitter on, reference default config",
-                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients", "team_help": bool(a.team_help == 1 or (a.team_help < 0 and (world > 1 or a.emulate_world > 1)))},
+                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients", "team_help": bool(a.team_help == 1)},
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"], "kernel_ms": main_res["kernel_ms"],
             "value_primary_only": (main_res.get("primary_only") or {}).get("value"), "primary_only": main_res.get("primary_only"),
-            "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None, "device_bytes": main_res.get("device_bytes"),
+            "multi_gpu": main_res.get("multi_gpu"), "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None, "device_bytes": main_res.get("device_bytes"),
             vkey[a.variant]: round(main_res["value"], 3), vkey["init" if a.variant == "trained" else "trained"]: (other or {}).get("value"),
             "note": "vs_baseline null: the reference publishes no throughput number; PSNR vs OptiX is unmeasurable here (no NVIDIA "
                     "hardware), parity is against the CPU oracle (tests/).",

@@ -418,6 +418,23 @@ struct Raytracer : torch::CustomClassHolder {
         pixel_mask = mask.contiguous();
         check(egr_debug_set_pixel_mask(ctx, pixel_mask.data_ptr<uint8_t>()), "debug_set_pixel_mask");
     }
+    // the six target images of a training view, channel-major ([C,H,W] contiguous fp32 CUDA tensors; an undefined / empty tensor = absent = zeros), written into
+    // the framebuffer's pixel-major target buffers for this context's own tiles in one launch (egr_set_targets_chw)
+    void set_targets_chw(c10::optional<Tensor> diffuse, c10::optional<Tensor> specular, c10::optional<Tensor> depth, c10::optional<Tensor> normal, c10::optional<Tensor> roughness,
+                         c10::optional<Tensor> f0) {
+        const c10::optional<Tensor> *in[6] = {&diffuse, &specular, &depth, &normal, &roughness, &f0};
+        const int64_t ch[6] = {3, 3, 1, 3, 1, 3};
+        Tensor keep[6];
+        const float *p[6];
+        for (int b = 0; b < 6; b++) {
+            p[b] = nullptr;
+            if (!in[b]->has_value() || (*in[b])->numel() == 0) continue;
+            TORCH_CHECK((*in[b])->is_cuda() && (*in[b])->numel() == ch[b] * width * height, "set_targets_chw: [C,H,W] CUDA tensor expected");
+            keep[b] = (*in[b])->to(torch::kFloat32).contiguous();
+            p[b] = keep[b].data_ptr<float>();
+        }
+        check(egr_set_targets_chw(ctx, p[0], p[1], p[2], p[3], p[4], p[5], current_stream()), "set_targets_chw");
+    }
     void set_rays_per_task(int64_t n) { TORCH_CHECK(egr_set_rays_per_task(ctx, (int)n) == 0, "set_rays_per_task: 0 (automatic), 16, 32 or 64 expected"); }
     void set_team_help(bool on) { TORCH_CHECK(egr_set_team_help(ctx, on ? 1 : 0) == 0, "set_team_help failed"); }
     void set_strands(int64_t n) { TORCH_CHECK(egr_set_strands(ctx, (int)n) == 0, "set_strands: 1..EGR_STRANDS (value at creation) expected"); }
@@ -513,6 +530,7 @@ struct Raytracer : torch::CustomClassHolder {
             .def("use_grad_delta", &Raytracer::use_grad_delta)
             .def("grad_delta_consumed", &Raytracer::grad_delta_consumed)
             .def("debug_set_pixel_mask", &Raytracer::debug_set_pixel_mask)
+            .def("set_targets_chw", &Raytracer::set_targets_chw)
             .def("set_exact_stats", &Raytracer::set_exact_stats)
             .def("set_strands", &Raytracer::set_strands)
             .def("set_team_help", &Raytracer::set_team_help)

@@ -1287,6 +1287,27 @@ __global__ void __launch_bounds__(EGR_WAVE) k_export_step_hits(DeviceView v, int
     }
 }
 
+// Target upload (the caller's six `buf.copy_(val.moveaxis(0, -1))` of gaussian_raytracer.py:109-137 as ONE launch): CHW images -> the framebuffer's HWC
+// target buffers, for the pixels of THIS rank's tiles only (a rank of an 8-way partition reads and writes an eighth of the 116 MB a whole
+// 1080p frame moves); a missing image writes zeros, like the reference's `buf.zero_()`.
+struct TargetImages {
+    const float *chw[6]; // diffuse, specular, depth, normal, roughness, f0
+};
+__global__ void __launch_bounds__(EGR_WAVE) k_upload_targets(DeviceView v, TargetImages t) {
+    const int lane = threadIdx.x;
+    const size_t P = v.num_pixels;
+    float *const dst[6] = {const_cast<float *>(v.fb.target_diffuse), const_cast<float *>(v.fb.target_specular), const_cast<float *>(v.fb.target_depth), const_cast<float *>(v.fb.target_normal), const_cast<float *>(v.fb.target_roughness), const_cast<float *>(v.fb.target_f0)}; // (the mirror of core/framebuffer.h declares the targets read-only for the launch)
+    constexpr int ch[6] = {3, 3, 1, 3, 1, 3};
+    for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
+        const TaskGeom tg = task_geom(v, task, lane);
+        if (!tg.inside) continue;
+#pragma unroll
+        for (int b = 0; b < 6; b++)
+#pragma unroll
+            for (int c = 0; c < ch[b]; c++) dst[b][(size_t)ch[b] * tg.pixel_id + c] = t.chw[b] ? t.chw[b][(size_t)c * P + tg.pixel_id] : 0.0f;
+    }
+}
+
 __global__ void k_copy3(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -1572,6 +1593,14 @@ void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s) {
     if (v.num_tasks) hipLaunchKernelGGL(k_export_step_hits, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev.p);
     EGR_HIP(hipMemcpyAsync(host_out, dev.p, bytes, hipMemcpyDeviceToHost, s));
     EGR_HIP(hipStreamSynchronize(s));
+}
+
+void egr_upload_targets(egr_context *c, const float *const chw[6], hipStream_t s) {
+    DeviceView v = egr_make_view(c);
+    v.pixel_mask = nullptr; // (targets of every pixel of the rank's tiles, whatever a debug mask says)
+    TargetImages t;
+    for (int b = 0; b < 6; b++) t.chw[b] = chw[b];
+    if (v.num_tasks) hipLaunchKernelGGL(k_upload_targets, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, t);
 }
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s) {

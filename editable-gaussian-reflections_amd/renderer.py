@@ -214,13 +214,9 @@ class GaussianRaytracer:
             camera.set_pose(viewpoint_camera.camera_center.contiguous(), R_c2w_blender.contiguous())
             self._export_param_values()
             framebuffer = self.cuda_module.get_framebuffer()
-            for name, val in (("target_diffuse", target_diffuse), ("target_specular", target_specular), ("target_depth", target_depth),
-                              ("target_normal", target_normal), ("target_roughness", target_roughness), ("target_f0", target_f0)):
-                buf = getattr(framebuffer, name)
-                if val is not None:
-                    buf.copy_(val.moveaxis(0, -1))  # CHW -> HWC (gaussian_raytracer.py:109-137)
-                else:
-                    buf.zero_()
+            # CHW -> HWC into framebuffer.target_*, zeros when absent (gaussian_raytracer.py:109-137: six copy_ / zero_ calls) - as ONE launch over the
+            # pixels of this rank's own tiles (egr_set_targets_chw; the kernel waits for nothing: a temporary's memory is stream-ordered)
+            self.cuda_module.set_targets_chw(target_diffuse, target_specular, target_depth, target_normal, target_roughness, target_f0)
         grads = torch.is_grad_enabled()
         if grads or force_update_bvh:
             # raytrace() follows with the same parameter values: one pass over the cloud writes the snapshot AND the live records

@@ -155,6 +155,13 @@ int egr_update_bvh_ex(egr_context *ctx, unsigned flags, void *hip_stream);
  * torch::autograd::GradMode::is_enabled() returned in the caller (metadata.h:29). Asynchronous. */
 int egr_raytrace(egr_context *ctx, int grads_enabled, void *hip_stream);
 
+/* Target upload (replaces the caller's six `framebuffer.target_*.copy_(image.moveaxis(0, -1))` of renderer/gaussian_raytracer.py:109-137, which
+ * stay valid): device pointers to channel-major fp32 images ([3][H][W] diffuse, specular, normal, f0; [1][H][W] depth, roughness), NULL = the
+ * target is absent and reads zero (the reference zeroes the buffer). ONE launch writes the framebuffer's pixel-major target buffers for the pixels
+ * of THIS context's partition only - the only target pixels its launches read. Asynchronous on the stream. */
+int egr_set_targets_chw(egr_context *ctx, const float *diffuse, const float *specular, const float *depth, const float *normal, const float *roughness,
+                        const float *f0, void *hip_stream);
+
 /* Raytracer::denoise (raytracer.cpp:96; optix/denoiser_wrapper.h:42-105: HDR image output_final + normal guide output_normal
  * -> output_denoised). The OptiX AI denoiser is a closed network; the stand-in is an edge-avoiding a-trous wavelet filter with
  * the same inputs and output (csrc/denoise.hip; parity with OptiX is unpinned). Env EGR_DENOISE=0 at creation: plain copy. */

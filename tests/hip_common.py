@@ -100,9 +100,8 @@ def grads_vs_oracle_listing_flipped_pixels(ren, rt, o, camera, tg, W, H, name, m
          consecutive composited hits within 4 ulps of each other in the oracle (their ORDER - hence their two weights - is decided by
          the last bits of t, where this build contracts fmas and the oracle does not; exact ties: by the list order, which is
          unspecified upstream);
-      3. assert there are at most `max_flipped` of them and that their 16x16 macro tiles are at most a quarter of the image, take those
-         tiles out ON BOTH SIDES (HIP: the product's own tile partition, one rank per macro tile, with the task shape of the whole-image
-         launch pinned - egr_set_rays_per_task - so the same kernel path runs; oracle: pixel mask) and assert < bar on everything else.
+      3. assert there are at most `max_flipped` of them, take exactly those PIXELS out ON BOTH SIDES (pixel masks: egr_debug_set_pixel_mask /
+         Oracle.set_pixel_mask - the same whole-image launch otherwise) and assert < bar on everything else.
     Whatever is listed, NO tensor may be further than `loose` (5e-3) from the oracle on all pixels.
     Returns (per-tensor errors over all pixels, per-tensor errors without the listed pixels, listed pixels)."""
     m = rt.cuda_module
@@ -135,35 +134,23 @@ def grads_vs_oracle_listing_flipped_pixels(ren, rt, o, camera, tg, W, H, name, m
     ys, xs = np.nonzero(flipped)
     listing = [(int(x), int(y), "+".join(k for k in why if why[k][y, x]), hits_h[:, y, x].tolist(), hits_o[:, y, x].tolist()) for y, x in zip(ys, xs)]
     assert 0 < len(listing) <= max_flipped, (name, err_all, listing[:20], len(listing))
-    mtx, mty = (W + 15) // 16, (H + 15) // 16
-    bad_tiles = sorted({(y // 16) * mtx + (x // 16) for x, y, *_ in listing})
-    assert len(bad_tiles) <= max(1, (mtx * mty + 3) // 4), (name, "listed pixels span more than a quarter of the image", bad_tiles, mtx * mty)
-    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    keep = ~np.isin((yy // 16) * mtx + (xx // 16), bad_tiles)
+    keep = ~flipped  # exactly the listed PIXELS are taken out, on both sides
     o.set_pixel_mask(keep)
     o.total_num_calls = k - 1
     ref_rest = o.raytrace(True, targets=tg)
     o.set_pixel_mask(None)
     rt.zero_grad()
     m.get_gaussians().total_weight.zero_()
-    par = importlib.import_module(PKG + ".parallel")
-    owner = par.tile_owner(W, H, mtx * mty).reshape(-1)  # one "rank" per macro tile
+    m.debug_set_pixel_mask(torch.from_numpy(keep.astype(np.uint8)).cuda())  # (a masked pixel is a pixel outside the image for every kernel of the launch)
     try:
-        m.set_rays_per_task(64)  # the whole-image launch ran 8x8 tasks; a one-tile rank would otherwise switch to 8x4
-        for t in range(mtx * mty):  # the launches of the kept tiles accumulate
-            if t in bad_tiles:
-                continue
-            m.set_partition(int(owner[t]), mtx * mty)
-            m.get_metadata().total_num_calls.fill_(k - 1)
-            ren.render(camera, rt)
+        m.get_metadata().total_num_calls.fill_(k - 1)
+        ren.render(camera, rt)
     finally:
-        m.set_partition(0, 1)
-        m.set_rays_per_task(0)
+        m.debug_set_pixel_mask(torch.empty(0, dtype=torch.uint8))
     torch.cuda.synchronize()
     gr_rest = hip_grads(rt)
     err_rest = {key: float(np.abs(gr_rest[key] - ref_rest[key]).max() / np.abs(ref[key]).max()) for key in live}
     worst_rest = max(err_rest.values())
-    report(name, worst_grad_all_pixels=f"{worst_all:.1e}", worst_grad_without_listed=f"{worst_rest:.1e}", flipped_pixels=listing,
-           macro_tiles_removed=f"{len(bad_tiles)}/{mtx * mty}")
+    report(name, worst_grad_all_pixels=f"{worst_all:.1e}", worst_grad_without_listed=f"{worst_rest:.1e}", flipped_pixels=listing)
     assert worst_rest < bar, (name, err_rest, listing)
     return err_all, err_rest, listing

@@ -1,0 +1,70 @@
+"""Worker of tests/test_hip_multirank.py::test_team_help_does_not_drift_training - two ranks that SHARE cuda:0 over gloo train the same
+cloud for 20 iterations (render in grad mode through the tile partition + the all-reduce of the launch's gradients, fused Adam step,
+another camera every iteration) three times: with team help ON (egr_set_team_help: the order of a ray's candidate list then depends on
+timing - the last bit of the total transmittance, the order of exact depth ties), with help OFF, and with help OFF once more (`twin`).
+A training loop is not reproducible to the last bit even without help: float atomics add a gaussian's contributions in varying order, and
+Adam with eps = 1e-15 (gaussian_model.py:338) turns a gradient element whose sign depends on that order into an update of +-lr. The bar
+is therefore relative: after 20 iterations the help-ON parameters may be no further from the help-OFF run than the help-OFF run is from
+its own twin (outlier elements beyond 1e-5 of a tensor's maximum: at most 3x the twin's + 20; 99.9 % of all elements within 1e-5).
+Prints TEAMHELP_OK on rank 0."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "editable-gaussian-reflections_amd"
+syn = importlib.import_module(PKG + ".synthetic")
+ren = importlib.import_module(PKG + ".renderer")
+tr = importlib.import_module(PKG + ".trainer")
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+W, H, N, ITERS = 480, 272, 30_000, 20
+LRS = dict(xyz=0.00016, normal=0.0025, roughness=0.0025, f0=0.0025, f_dc=0.005, opacity=0.025, scaling=0.005, rotation=0.001)  # config.py:62-72
+g0 = syn.make_scene(N, "trained", seed=33)
+tg = syn.make_targets(W, H)
+images = {k + "_image": torch.tensor(v).cuda().moveaxis(-1, 0).contiguous() for k, v in tg.items()}
+eyes = [(-1.7, -1.2, 0.4), (-1.5, 1.1, 0.2), (-0.4, -1.6, 0.6), (-1.8, 0.0, -0.3), (-1.0, -1.0, 0.9)]
+cams = [ren.camera_from_c2w(np.asarray(e, np.float32), syn.look_at(e, (1.2, 0.4 - 0.2 * i, -0.7)).astype(np.float32), 0.6911, **images) for i, e in enumerate(eyes)]
+
+
+def train(team_help):
+    pc = ren.GaussianParams(g0)
+    rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=60_000_000, ppll_backward_size=40_000_000, rank=rank, world_size=world, team_help=team_help)
+    step = tr.FusedTrainStep(pc, rt, LRS, scale_decay=0.9999)
+    rt.cuda_module.get_metadata().total_num_calls.zero_()
+    for it in range(ITERS):
+        ren.render(cams[it % len(cams)], rt)
+        assert rt.cuda_module.get_counters()[11] == 0
+        step.step()
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in pc.parameters()]
+
+
+on, off, twin = train(True), train(False), train(False)
+
+
+def compare(a, b):
+    out, within = 0, []
+    for x, y in zip(a, b):
+        d = (x - y).abs() / float(y.abs().max())
+        out += int((d > 1e-5).sum())
+        within.append(float((d <= 1e-5).float().mean()))
+    return out, min(within)
+
+
+o_on, w_on = compare(on, off)
+o_tw, w_tw = compare(twin, off)
+print(f"[rank {rank}] elements beyond 1e-5 after {ITERS} iterations: help on vs off {o_on} (share within: {w_on:.6f}), off vs off {o_tw} (share within: {w_tw:.6f})", flush=True)
+assert o_on <= 3 * o_tw + 20, (o_on, o_tw)
+assert w_on >= 0.999, w_on
+dist.barrier()
+if rank == 0:
+    print("TEAMHELP_OK", o_on, o_tw, flush=True)
+dist.destroy_process_group()
