@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--cpu-sample", default="480x270")
     p.add_argument("--primary-steps", type=int, default=30, help="timed iterations of the primary-only (num_bounces = 0) leg; 0 skips it")
     p.add_argument("--profile-steps", type=int, default=9, help="extra untimed launches with per-kernel HIP events")
-    p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 3 from four tiles per wave slot, else 1); the per-kernel profile pass always uses 1")
+    p.add_argument("--strands", type=int, default=0, help="tile slices traced on separate HIP streams (0 = library default: 1); the per-kernel profile pass always uses 1")
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
     p.add_argument("--emulate-rank", type=int, default=0, help="which rank's tiles --emulate-world traces")
     p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
@@ -295,7 +295,7 @@ def main():
                          "Hc_source": "one exact-statistics launch of the same frame on the GPU (cube boxes; reference-defined count)",
                          "inside_ellipsoid_per_ray": [round(cand_eval[s] / max(rays[s], 1), 2) for s in range(3)],
                          "Kc_per_ray": [round(comp[s] / max(rays[s], 1), 2) for s in range(3)],
-                         "strands_timed_region": a.strands if a.strands > 0 else "auto (3 from four tiles per wave slot, else 1)", "strands_profile_pass": 1,
+                         "strands_timed_region": a.strands if a.strands > 0 else 1, "strands_profile_pass": 1,
                          "whole_launch_GBps": round(sum(cands.values()) / (kern.get("raytrace_total", 1e9) * 1e-3) / 1e9, 2),
                          "other_kernels": [roof_of(k) for k in cands if k != dom and k in kern]})
             res["device_bytes"] = int(cc[14])

@@ -1518,7 +1518,10 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
         // (no explicit egr_set_strands: all strands when the rank has at least four tiles per wave slot; with fewer - a rank of a
         // multi-GPU partition - concurrent chains only delay each other's heaviest tiles: 4.66 / 4.85 / 4.97 ms with 1 / 2 / 3
         // strands for rank 0 of an 8-way partition, 18.7 / 18.3 / 18.0 ms for the whole image)
-        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : ((uint64_t)(v.num_tasks >> (v.task_shift - 2u)) >= 4ull * c->num_slots ? c->strands : 1); // (counted in 8x8 tiles)
+        // (round 5: ONE strand unless egr_set_strands asks for more. Strands paid while the chains ended in long tails; with the backward tasks costliest
+        // first and today's forward chain, interleaved same-box runs of the whole image give 6.73-6.90 / 11.13 ms per iteration with one strand against
+        // 6.94-6.97 / 11.33-11.38 with three - concurrent chains delay each other's tiles more than they fill tails)
+        const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : 1;
         const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
         static const int bwd_team_env = getenv("EGR_BWD_TEAM_HELP") ? atoi(getenv("EGR_BWD_TEAM_HELP")) : -1; // (experiments: 0 / 1 force the choice)
         const bool backward_teams = bwd_team_env >= 0 ? bwd_team_env != 0 : (c->team_help == 1 || (c->world > 1 && (uint64_t)(v.num_tasks >> (v.task_shift - 2u)) < 2ull * c->num_slots)); // (egr_set_team_help(1) takes the teams of both chains: tests/test_hip_parity.py)

@@ -203,8 +203,8 @@ int egr_set_exact_stats(egr_context *ctx, int enable);
 /* Strands (not in the reference): egr_raytrace cuts this context's tiles into `strands` slices and runs their step kernels on
  * separate internal HIP streams (forked from / joined to the caller's stream), so that one slice's persistent-wave tail is
  * filled by another slice's next kernel. 1 = everything on the caller's stream (per-kernel timings are then exclusive).
- * Accepts 1..(value at creation: env EGR_STRANDS, default 3); returns 1 otherwise. Without a call, a launch uses all strands
- * when the rank has at least four tiles per resident wave slot and one strand below that (multi-GPU partitions). */
+ * Accepts 1..(value at creation: env EGR_STRANDS, default 3); returns 1 otherwise. Without a call a launch uses ONE strand (round 5:
+ * with today's chains three strands measure 1-3 % slower than one; the mechanism stays for experiments). */
 int egr_set_strands(egr_context *ctx, int strands);
 
 /* Task shape (not in the reference): pixels one wave traces together. 64 = 8x8 (default), 32 = 8x4, 16 = 4x4; 0 = automatic (64, or

@@ -179,7 +179,7 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
     training loss weights), "grad check vs ref" AT THE CONFIG'S OWN SIZE. Both sides trace the pixels of 48 macro tiles of the
     full-size frame - same gaussians, same camera, same rays as the whole image - through a PIXEL MASK (oracle: set_pixel_mask; HIP:
     egr_debug_set_pixel_mask, a masked pixel is a pixel outside the image for every kernel of the launch); the HIP launch is a
-    whole-image launch of the product (8x8 tasks, strands), its gradients accumulate like the reference's atomicAdds over pixels
+    whole-image launch of the product (8x8 tasks), its gradients accumulate like the reference's atomicAdds over pixels
     (backward_pass.cu:89-220).
 
     What fp32 allows at this scale (gaussians of 0.01 units, 20-70 composited hits per primary ray, three steps): whether a ray
