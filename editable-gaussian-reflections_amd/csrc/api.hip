@@ -143,7 +143,7 @@ int egr_set_rays_per_task(egr_context *c, int rays_per_task) {
 }
 
 int egr_set_team_help(egr_context *c, int on) {
-    if (!c || !(on == 0 || on == 1)) return 1;
+    if (!c || !(on == 0 || on == 1 || on == -1)) return 1;
     c->team_help = on;
     return 0;
 }

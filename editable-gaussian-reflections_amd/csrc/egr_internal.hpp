@@ -198,7 +198,7 @@ struct egr_context {
     float *state = nullptr;
     uint32_t state_stride = 0;
     uint32_t num_tasks_total = 0; // 8x8 wave tiles in the whole image (a 16x16 macro tile = 4 of them = 256 rays of ray state)
-    int team_help = 0;            // egr_set_team_help / env EGR_TEAM_HELP: 1 = waves without tiles help their team mates' walks (forward outputs then depend on timing in their last bits)
+    int team_help = -1;           // egr_set_team_help / env EGR_TEAM_HELP: 1 = waves without tiles help their team mates' walks, 0 = never, -1 (default) = automatic: for under-filled ranks of a partition only (egr_team_help_on)
     int rays_per_task = 0;        // 0: automatic (64; 32 for a rank of a partition with fewer than two 8x8 tiles per wave slot); env EGR_RAYS_PER_TASK
     uint32_t *task_macro = nullptr; // device table of the current partition's tile order: one of task_orders[].table
     struct TaskOrder {              // tile orders built so far (a partitioned trainer flips between (rank, world) for training launches and
@@ -247,6 +247,7 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
 uint32_t egr_num_tasks_for_rank(const egr_context *c);
 void egr_build_task_order(egr_context *c);
 DeviceView egr_make_view(const egr_context *c);
+bool egr_team_help_on(const egr_context *c); // the forward chain of the next launch runs as teams with help
 // timing helpers (api.hip)
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s);
 void egr_stamp_end(egr_context *c, hipStream_t s);

@@ -13,7 +13,7 @@
 //     (ray, node) pairs and one buffer of (ray, leaf) pairs in LDS: lane m of group g tests child slot m of the g-th popped node, ballots
 //     compact the hits, and 64 leaf pairs at a time are evaluated with one lane per pair) - pair_walk below, frustum walk in forward_task.inc;
 //   * the forward chain exists as single-wave workgroups and as TEAMS of waves with a shared LDS in which waves without tiles walk pairs
-//     their team mates offer (egr_set_team_help: several waves on one heavy tile, for under-filled ranks of a multi-GPU partition);
+//     their team mates offer (egr_set_team_help; automatic: on for under-filled ranks of a multi-GPU partition - several waves on one heavy tile);
 //   * the reference's global per-pixel linked list (one same-address atomic per candidate, 36 B entries, pointer chasing)
 //     is replaced by a per-resident-wave candidate scratch, one contiguous run per lane ([lane][k]) with bump-allocated
 //     extension blocks for the rare long list; it is reused tile after tile;
@@ -243,8 +243,8 @@ EGR_DI bool hits_unit_cube_exact(f3 lo, f3 ld, float tmin, float tmax) {
 // of it (up to EGR_BOX pairs) on offer. The taker walks those pairs on its own stack and leaf buffer against the OWNER's ray table, its
 // accepted candidates take slots of the owner's lists through the owner's LDS counters - exactly what the owner would have done with
 // them, in another order (the list order of a ray is an implementation matter) - and it may pass part of them on. A rank
-// of an 8-way partition has one tile per wave slot and its launch lasts as long as its heaviest tile's chain. Off unless
-// the caller asks (egr_set_team_help): a ray's list order then depends on timing.
+// of an 8-way partition has one tile per wave slot and its launch lasts as long as its heaviest tile's chain. Automatic (egr_team_help_on):
+// on for such ranks, off for a whole image unless the caller asks - a ray's list order depends on timing, which no output sees except through the order of EXACT depth ties.
 #ifndef EGR_TEAM
 #define EGR_TEAM 16 // waves per workgroup of the forward chain's team build: the chain exists twice, as teams of this size for launches with
                     // egr_set_team_help(1) and as single-wave workgroups for all others (a team's LDS stays allocated until its last wave
@@ -1466,6 +1466,15 @@ void egr_trace_alloc(egr_context *c) {
     egr_build_task_order(c);
 }
 
+// Team help of the next launch: what the caller set, or - automatic - on for a rank of a partition with fewer than two 8x8 tiles per wave slot (its launch
+// lasts as long as its heaviest tile; help takes 5-8 % off its iteration), off for everything else (a whole image gains 6 % / 3 % of its forward chain too,
+// but then the order of EXACT depth ties of bounce rays - 0.1 % of the pixels of a 1080p frame hold one - varies from run to run, as it does upstream).
+bool egr_team_help_on(const egr_context *c) {
+    if (EGR_TEAM <= 1) return false;
+    if (c->team_help >= 0) return c->team_help == 1;
+    return c->world > 1 && egr_num_tasks_for_rank(c) < 2u * c->num_slots;
+}
+
 DeviceView egr_make_view(const egr_context *c) {
     DeviceView v{};
     v.width = c->width, v.height = c->height;
@@ -1481,13 +1490,13 @@ DeviceView egr_make_view(const egr_context *c) {
     // (pair walk), so exactly tied depths may composite in another order than with 8x8 tasks (documented deviation (a)).
     const uint32_t tiles = egr_num_tasks_for_rank(c);
     uint32_t rpt = c->rays_per_task == 16 || c->rays_per_task == 32 || c->rays_per_task == 64 ? (uint32_t)c->rays_per_task
-                   : (c->world > 1 && tiles < 2u * c->num_slots && c->team_help != 1 ? 32u : 64u); // (with team help the heavy tile's walk is shared anyway, and whole 8x8 tiles keep all lanes busy in the per-ray phases: 3.08-3.12 against 3.17-3.21 ms trained-like, 3.50-3.55 against 3.48-3.51 ms dense-init per iteration of rank 0 of 8)
+                   : (c->world > 1 && tiles < 2u * c->num_slots && !egr_team_help_on(c) ? 32u : 64u); // (with team help the heavy tile's walk is shared anyway, and whole 8x8 tiles keep all lanes busy in the per-ray phases: 3.08-3.12 against 3.17-3.21 ms trained-like, 3.50-3.55 against 3.48-3.51 ms dense-init per iteration of rank 0 of 8)
     v.rays_per_task = rpt, v.task_shift = rpt == 64u ? 2u : rpt == 32u ? 3u : 4u;
     v.num_tasks = tiles << (v.task_shift - 2u);
     v.task_begin = 0, v.task_count = v.num_tasks, v.queues = c->queues, v.num_strands = (uint32_t)c->strands;
     v.task_macro = c->task_macro;
-    // (help changes the ORDER in which a ray's candidates enter its list, never the set: off unless the caller asks - egr_set_team_help)
-    v.team_help = EGR_TEAM > 1 && c->team_help == 1 ? 1 : 0;
+    // (help changes the ORDER in which a ray's candidates enter its list, never the set; egr_team_help_on)
+    v.team_help = egr_team_help_on(c) ? 1 : 0;
     v.g = c->g, v.cfg = c->cfg, v.cam = c->cam, v.fb = c->fb, v.meta = c->meta, v.stats = c->stats;
     v.wnodes = c->wnodes, v.stack_spill = c->stack_spill, v.gid_of_pos = c->vals_out, v.pos_of_gid = c->pos_of_gid, v.frame = c->frame, v.out_of_frame = c->out_of_frame, v.inst_w = c->inst_w, v.inst_m = c->inst_m, v.grad_rows = c->grad_rows, v.app = c->app, v.bsph = c->bsph;
     v.cand_keys = c->cand_keys, v.cand_vals = c->cand_vals, v.cand_cap = c->cand_cap, v.num_slots = c->num_slots;
@@ -1524,7 +1533,7 @@ void egr_trace_launch(egr_context *c, bool grads, bool live_fresh, hipStream_t s
         const int want = c->strands_active > 0 ? std::min(c->strands_active, c->strands) : 1;
         const int S = (v.num_tasks >= 8u * (uint32_t)want) ? want : 1;
         static const int bwd_team_env = getenv("EGR_BWD_TEAM_HELP") ? atoi(getenv("EGR_BWD_TEAM_HELP")) : -1; // (experiments: 0 / 1 force the choice)
-        const bool backward_teams = bwd_team_env >= 0 ? bwd_team_env != 0 : (c->team_help == 1 || (c->world > 1 && (uint64_t)(v.num_tasks >> (v.task_shift - 2u)) < 2ull * c->num_slots)); // (egr_set_team_help(1) takes the teams of both chains: tests/test_hip_parity.py)
+        const bool backward_teams = bwd_team_env >= 0 ? bwd_team_env != 0 : (v.team_help == 1 || (c->world > 1 && (uint64_t)(v.num_tasks >> (v.task_shift - 2u)) < 2ull * c->num_slots)); // (egr_set_team_help(1) takes the teams of both chains: tests/test_hip_parity.py)
         if (S > 1) EGR_HIP(hipEventRecord(c->ev_fork, s));
         for (int st = 0; st < S; st++) {
             hipStream_t ls = S > 1 ? c->strand_stream[st] : s;

@@ -82,7 +82,7 @@ class GaussianRaytracer:
     EVAL_MODES = ("gather", "full_image")
 
     def __init__(self, pc, image_width: int, image_height: int, ppll_forward_size=None, ppll_backward_size=None, rank=0, world_size=1,
-                 gather_buffers=None, team_help=False, eval_mode="gather", group=None):
+                 gather_buffers=None, team_help=None, eval_mode="gather", group=None):
         """`eval_mode` (partitioned tracers only; also a per-call argument): what a no-grad render does.
         "gather": every rank traces its own tiles and the images are completed with ONE all-gather - a COLLECTIVE: every rank of
         `group` must make the call (needs a process group whose size equals `world_size`; without one the rank traces the whole image).
@@ -108,8 +108,8 @@ class GaussianRaytracer:
             self.cuda_module.resize(n)
         self.rank, self.world_size = rank, world_size
         self.import_grads = True  # False: a fused host step (trainer.FusedTrainStep) imports the raytracer gradients itself
-        if team_help:  # several waves on one heavy tile (egr_set_team_help): shortens the tail of a partition's rank; forward outputs then depend on timing in their last bits
-            self.cuda_module.set_team_help(True)
+        if team_help is not None:  # several waves on one heavy tile (egr_set_team_help; library default: automatic = under-filled ranks of a partition). Only the order of EXACT depth ties depends on it
+            self.cuda_module.set_team_help(bool(team_help))
         if world_size > 1:
             self.cuda_module.set_partition(rank, world_size)
             self.cuda_module.use_grad_delta(True)  # grad launches write a per-launch buffer (the first after a fold stores, further ones add): see all_reduce_grads

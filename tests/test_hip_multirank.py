@@ -46,7 +46,7 @@ def test_exchange_step_through_rccl_at_world_size_1():
 def test_bench_two_ranks_prints_one_line():
     """bench.py under torch.distributed.run exactly as the driver launches it (reduced sizes, gloo because both ranks sit on cuda:0)."""
     r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--width", "480", "--height", "272",
-                 "--gaussians", "30000", "--profile-steps", "1", "--no-cpu-baseline"], 29533, env_extra={"EGR_DIST_BACKEND": "gloo"})
+                 "--gaussians", "30000", "--profile-steps", "1", "--no-cpu-baseline"], 29533, env_extra={"EGR_DIST_BACKEND": "gloo", "EGR_TEAM_HELP": "1"})  # (the product's default for such ranks: help on)
     assert r.returncode == 0, r.stdout[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

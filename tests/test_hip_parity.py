@@ -644,8 +644,8 @@ def test_strands_do_not_change_results(ren, orc, syn):
 def test_team_help_changes_the_list_order_only(ren, orc, syn):
     """egr_set_team_help(1): waves without tiles walk (ray, node) pairs their team mates offer (several waves on one heavy tile). The SET of
     candidates of every ray stays what it was - both per-pixel statistics and every counter equal the run without help - only the order in
-    which they enter the ray's list may change: the total-transmittance product rounds differently in its last bit, everything else follows
-    from that (a small image leaves most waves of every team without a tile, so help is the rule here, not the exception). The switch also
+    which they enter the ray's list may change - and that order reaches no output: the depth selection orders by (t, list index), so only EXACT
+    depth ties could composite in another order, and the total transmittance is an fp64 product rounded once (a small image leaves most waves of every team without a tile, so help is the rule here, not the exception). The switch also
     takes the BACKWARD chain's team build (a partition's under-filled rank gets it without asking: its waves without tiles take batches of
     their team mates' bounce hits): the gradients of the runs with help are compared with the run without."""
     W, H = 96, 64
@@ -675,7 +675,9 @@ def test_team_help_changes_the_list_order_only(ren, orc, syn):
         for k in OUT_KEYS:
             d = np.abs(run[0][k] - ref[0][k]).max() / (np.abs(ref[0][k]).max() + 1e-30)
             worst = max(worst, d)
-            assert d < 2e-5, (k, d)
+            # (round 5: the total transmittance is an fp64 product rounded once, so the list order no longer reaches any output: without exact depth ties -
+            # this scene has none - the images of a run with help are the images of the run without, bit for bit)
+            assert np.array_equal(run[0][k], ref[0][k]), (k, d)
         for k in GRAD_KEYS:
             assert np.abs(run[1][k] - ref[1][k]).max() / (np.abs(ref[1][k]).max() + 1e-30) < 1e-4, k
     print(f"REPORT team help: worst output difference against the run without help {worst:.2e} of the buffer's maximum")
