@@ -682,6 +682,7 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
         if (tq == 0xFFFFFFFFu) break;
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 9 // diagnostic build: stamps of the WHOLE chain of a task (start, end of every step) in its first pixels
         unsigned long long chain_t[EGR_NSTEPS + 1] = {__builtin_amdgcn_s_memrealtime(), 0ull, 0ull, 0ull};
+        uint32_t chain_leaves = 0u;
 #endif
 #ifdef EGR_TRAVERSAL_STATS
         const unsigned long long tchain0 = __builtin_amdgcn_s_memtime();
@@ -725,6 +726,7 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
         {
             const TaskGeom ctg = task_geom(v, v.task_begin + tq, lane);
             if (lane <= EGR_NSTEPS && ctg.inside) v.stats.num_traversed_per_pixel[ctg.pixel_id] = (int32_t)(chain_t[lane] & 0x7FFFFFFFull);
+            if (lane == 4 && ctg.inside) v.stats.num_traversed_per_pixel[ctg.pixel_id] = (int32_t)chain_leaves;
         }
 #endif
     }

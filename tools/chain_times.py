@@ -15,7 +15,8 @@ for call in [int(x) for x in os.environ.get("CALLS", "10,11").split(",")]:
     m.get_metadata().total_num_calls.fill_(call - 1)
     with torch.no_grad(): rt(camera)
     torch.cuda.synchronize()
-    t = m.get_stats().num_traversed_per_pixel.view(H // 8, 8, W // 8, 8)[:, 0, :, :4].cpu().numpy().astype(np.int64).reshape(-1, 4) * 0.01  # us
+    raw = m.get_stats().num_traversed_per_pixel.view(H // 8, 8, W // 8, 8)[:, 0, :, :5].cpu().numpy().astype(np.int64).reshape(-1, 5)
+    t, leaves = raw[:, :4] * 0.01, raw[:, 4]  # us; leaves the tile's primary step evaluated
     d = np.diff(t, axis=1)  # per step
     tot = t[:, 3] - t[:, 0]
     ok = (d >= 0).all(1) & (t[:, 0] > 0) & (tot > 0)  # (tiles of other ranks carry no stamps)
@@ -36,4 +37,6 @@ for call in [int(x) for x in os.environ.get("CALLS", "10,11").split(",")]:
     blk = np.minimum(3, tx * 4 // (W // 8)) + 4 * np.minimum(1, ty * 2 // (H // 8))
     per_chunk = [np.flatnonzero(blk == b)[np.argsort(-dur[blk == b])] for b in range(8)]
     inter = [int(x) for tup in zip(*[list(p) + [-1] * (max(map(len, per_chunk)) - len(p)) for p in per_chunk]) for x in tup if x >= 0]
+    lv = leaves[ok]
+    print(f"   leaves per tile mean {lv.mean():.1f} max {lv.max()}; correlation of the chain's duration with the leaf count {np.corrcoef(lv, dur)[0, 1]:.3f}, of the primary step's {np.corrcoef(lv, d[ok][:, 0])[0, 1]:.3f}; list schedule in descending LEAF order {sim(np.argsort(-lv)):.0f} us", flush=True)
     print(f"   span {e.max():.0f} us | sum / {slots} slots {dur.sum() / slots:.0f} | list schedule: start order {sim(np.argsort(s)):.0f}, longest first {sim(np.argsort(-dur)):.0f}, longest first inside each XCD block {sim(inter):.0f} | last start {s.max():.0f}", flush=True)
