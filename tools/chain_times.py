@@ -39,4 +39,10 @@ for call in [int(x) for x in os.environ.get("CALLS", "10,11").split(",")]:
     inter = [int(x) for tup in zip(*[list(p) + [-1] * (max(map(len, per_chunk)) - len(p)) for p in per_chunk]) for x in tup if x >= 0]
     lv = leaves[ok]
     print(f"   leaves per tile mean {lv.mean():.1f} max {lv.max()}; correlation of the chain's duration with the leaf count {np.corrcoef(lv, dur)[0, 1]:.3f}, of the primary step's {np.corrcoef(lv, d[ok][:, 0])[0, 1]:.3f}; list schedule in descending LEAF order {sim(np.argsort(-lv)):.0f} us", flush=True)
+    nat = np.argsort(s)
+    for kk in (1.25, 1.5, 2.0, 3.0):
+        heavy = lv > kk * lv.mean()
+        order = list(np.flatnonzero(heavy)[np.argsort(-lv[heavy])]) + [i for i in nat if not heavy[i]]
+        print(f"   tiles with more than {kk} x the mean leaf count first (descending, {int(heavy.sum())} tiles), the rest in start order: {sim(order):.0f} us", flush=True)
+    np.save(os.environ.get("CHAIN_DUMP", "/tmp/chain_dump") + f"_{os.environ.get('VARIANT', 'init')}.npy", np.stack([lv, dur, d[ok][:, 0], d[ok][:, 1], d[ok][:, 2], s]))
     print(f"   span {e.max():.0f} us | sum / {slots} slots {dur.sum() / slots:.0f} | list schedule: start order {sim(np.argsort(s)):.0f}, longest first {sim(np.argsort(-dur)):.0f}, longest first inside each XCD block {sim(inter):.0f} | last start {s.max():.0f}", flush=True)
