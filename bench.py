@@ -50,7 +50,7 @@ def parse():
     p.add_argument("--emulate-world", type=int, default=0, help="diagnostic: trace only rank 0's tiles of an N-rank partition on this one GPU (no collective)")
     p.add_argument("--emulate-rank", type=int, default=0, help="which rank's tiles --emulate-world traces")
     p.add_argument("--prewarm-seconds", type=float, default=0.0, help="keep the GPU busy with a torch matmul loop this long before the first launch (clock ramp; used under rocprofv3 so that the per-kernel averages are not carried by cold launches)")
-    p.add_argument("--team-help", type=int, default=-1, help="egr_set_team_help: waves without tiles help their team mates' walks (1 / 0); -1 = the product's default (automatic: on for under-filled ranks of a partition, off for a whole image; the list order reaches no output except the order of exact depth ties)")
+    p.add_argument("--team-help", type=int, default=-1, help="egr_set_team_help: waves without tiles help their team mates' walks (1 / 0); -1 = the product's default (on: the list order reaches no output except the order of exact depth ties of bounce rays)")
     p.add_argument("--ppll-forward", type=int, default=400_000_000, help="forward capacity in the reference's 36-B entries (its own test uses 300M at 1536x1024; its default is 180M)")
     p.add_argument("--ppll-backward", type=int, default=300_000_000, help="backward capacity (reference default 120M)")
     p.add_argument("--forward-only", action="store_true", help="no-grad render instead of a training iteration (implied by --config B)")
@@ -193,11 +193,10 @@ def main():
             for _ in range(5):
                 one_step()
 
-        # the same iteration with team help ON (egr_set_team_help(1): waves without tiles walk pairs their team mates offer). A whole image runs without
-        # it by default - its launches then are reproducible bit for bit, with help the order of exact depth ties of bounce rays is timing - so the
-        # headline `value` is the default; this leg shows what the switch is worth on the same box in the same process
+        # the same iteration with team help OFF (egr_set_team_help(0): single-wave workgroups, every launch reproducible bit for bit - with help, the
+        # product's default, the order of exact depth ties of bounce rays is timing): what the default is worth on the same box in the same process
         if world == 1 and a.emulate_world <= 1 and a.team_help < 0 and a.primary_steps > 0 and not a.forward_only:
-            m.set_team_help(True)
+            m.set_team_help(False)
             for _ in range(15):
                 one_step()
             barrier()
@@ -208,9 +207,9 @@ def main():
                 one_step()
             barrier()
             dth = time.perf_counter() - t0
-            res["team_help_on"] = {"value": round(float(m.get_counters()[9]) / dth / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dth / a.primary_steps * 1e3, 4), "steps": a.primary_steps,
-                                   "note": "egr_set_team_help(1) on the whole image: the order of exact depth ties of bounce rays then depends on timing (as upstream); off by default for a whole image"}
-            m.set_team_help_auto()
+            res["team_help_off"] = {"value": round(float(m.get_counters()[9]) / dth / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dth / a.primary_steps * 1e3, 4), "steps": a.primary_steps,
+                                    "note": "egr_set_team_help(0): no wave helps another; launches reproducible bit for bit"}
+            m.set_team_help(True)
             for _ in range(5):
                 one_step()
 
@@ -361,7 +360,7 @@ def main():
         ov = "init" if a.variant == "trained" else "trained"
         r2 = run_variant(ov, True, False)
         other = {"variant": ov, "value": round(r2["value"], 3), "unit": "Mrays/s", "ms_per_step": round(r2["ms_per_step"], 4), "status": r2["status"],
-                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"], "device_bytes": r2.get("device_bytes"), "primary_only": r2.get("primary_only"), "team_help_on": r2.get("team_help_on")}
+                 "roofline": r2["roofline"], "kernel_ms": r2["kernel_ms"], "device_bytes": r2.get("device_bytes"), "primary_only": r2.get("primary_only"), "team_help_off": r2.get("team_help_off")}
     if rank == 0:
         line = {
             "metric": "Mrays/s fwd+bwd @1080p, 1M Gaussians" if a.config == "C" and not a.forward_only else "Mrays/s fwd-only @1080p",
@@ -370,10 +369,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {a.config}: synthetic dense-init room+spheres cloud, HEADLINE variant = {a.variant} ({label[a.variant]}; "
                                    f"the other variant is in `other_variant`), N={N}, {W}x{H}, {what}, num_bounces={a.bounces}, jitter on, reference default config",
-                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients", "team_help": "product default (automatic: ranks of a partition with fewer than two tiles per wave slot)" if a.team_help < 0 else bool(a.team_help == 1)},
+                       "variant": a.variant, "gaussians": N, "width": W, "height": H, "parallelism": f"image tiles x{world} + 1 all-reduce of the launch's [22N] gradients", "team_help": "product default (on)" if a.team_help < 0 else bool(a.team_help == 1)},
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"], "kernel_ms": main_res["kernel_ms"],
             "value_primary_only": (main_res.get("primary_only") or {}).get("value"), "primary_only": main_res.get("primary_only"),
-            "value_team_help_on": (main_res.get("team_help_on") or {}).get("value"), "team_help_on": main_res.get("team_help_on"),
+            "value_team_help_off": (main_res.get("team_help_off") or {}).get("value"), "team_help_off": main_res.get("team_help_off"),
             "multi_gpu": main_res.get("multi_gpu"), "other_variant": other, "status": main_res["status"], "psnr_vs_optix": None, "device_bytes": main_res.get("device_bytes"),
             vkey[a.variant]: round(main_res["value"], 3), vkey["init" if a.variant == "trained" else "trained"]: (other or {}).get("value"),
             "note": "vs_baseline null: the reference publishes no throughput number; PSNR vs OptiX is unmeasurable here (no NVIDIA "

@@ -198,7 +198,7 @@ struct egr_context {
     float *state = nullptr;
     uint32_t state_stride = 0;
     uint32_t num_tasks_total = 0; // 8x8 wave tiles in the whole image (a 16x16 macro tile = 4 of them = 256 rays of ray state)
-    int team_help = -1;           // egr_set_team_help / env EGR_TEAM_HELP: 1 = waves without tiles help their team mates' walks, 0 = never, -1 (default) = automatic: for under-filled ranks of a partition only (egr_team_help_on)
+    int team_help = 1;            // egr_set_team_help / env EGR_TEAM_HELP: 1 (default) = waves without tiles help their team mates' walks, 0 = never, -1 = only for under-filled ranks of a partition (egr_team_help_on)
     int rays_per_task = 0;        // 0: automatic (64; 32 for a rank of a partition with fewer than two 8x8 tiles per wave slot); env EGR_RAYS_PER_TASK
     uint32_t *task_macro = nullptr; // device table of the current partition's tile order: one of task_orders[].table
     struct TaskOrder {              // tile orders built so far (a partitioned trainer flips between (rank, world) for training launches and

@@ -437,7 +437,7 @@ struct Raytracer : torch::CustomClassHolder {
     }
     void set_rays_per_task(int64_t n) { TORCH_CHECK(egr_set_rays_per_task(ctx, (int)n) == 0, "set_rays_per_task: 0 (automatic), 16, 32 or 64 expected"); }
     void set_team_help(bool on) { TORCH_CHECK(egr_set_team_help(ctx, on ? 1 : 0) == 0, "set_team_help failed"); }
-    void set_team_help_auto() { TORCH_CHECK(egr_set_team_help(ctx, -1) == 0, "set_team_help_auto failed"); } // the default: on for under-filled ranks of a partition only
+    void set_team_help_auto() { TORCH_CHECK(egr_set_team_help(ctx, -1) == 0, "set_team_help_auto failed"); } // on for under-filled ranks of a partition only (egr_set_team_help(-1))
     void set_strands(int64_t n) { TORCH_CHECK(egr_set_strands(ctx, (int)n) == 0, "set_strands: 1..EGR_STRANDS (value at creation) expected"); }
     std::vector<int64_t> get_counters() { // synchronises
         egr_counters c{};

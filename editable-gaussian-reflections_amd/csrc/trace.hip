@@ -13,7 +13,7 @@
 //     (ray, node) pairs and one buffer of (ray, leaf) pairs in LDS: lane m of group g tests child slot m of the g-th popped node, ballots
 //     compact the hits, and 64 leaf pairs at a time are evaluated with one lane per pair) - pair_walk below, frustum walk in forward_task.inc;
 //   * the forward chain exists as single-wave workgroups and as TEAMS of waves with a shared LDS in which waves without tiles walk pairs
-//     their team mates offer (egr_set_team_help; automatic: on for under-filled ranks of a multi-GPU partition - several waves on one heavy tile);
+//     their team mates offer (egr_set_team_help, on by default: several waves on one heavy tile - the tail of every launch, most of an under-filled rank's);
 //   * the reference's global per-pixel linked list (one same-address atomic per candidate, 36 B entries, pointer chasing)
 //     is replaced by a per-resident-wave candidate scratch, one contiguous run per lane ([lane][k]) with bump-allocated
 //     extension blocks for the rare long list; it is reused tile after tile;
@@ -243,8 +243,8 @@ EGR_DI bool hits_unit_cube_exact(f3 lo, f3 ld, float tmin, float tmax) {
 // of it (up to EGR_BOX pairs) on offer. The taker walks those pairs on its own stack and leaf buffer against the OWNER's ray table, its
 // accepted candidates take slots of the owner's lists through the owner's LDS counters - exactly what the owner would have done with
 // them, in another order (the list order of a ray is an implementation matter) - and it may pass part of them on. A rank
-// of an 8-way partition has one tile per wave slot and its launch lasts as long as its heaviest tile's chain. Automatic (egr_team_help_on):
-// on for such ranks, off for a whole image unless the caller asks - a ray's list order depends on timing, which no output sees except through the order of EXACT depth ties.
+// of an 8-way partition has one tile per wave slot and its launch lasts as long as its heaviest tile's chain. On by default
+// (egr_team_help_on) - a ray's list order depends on timing, which no output sees except through the order of EXACT depth ties.
 #ifndef EGR_TEAM
 #define EGR_TEAM 16 // waves per workgroup of the forward chain's team build: the chain exists twice, as teams of this size for launches with
                     // egr_set_team_help(1) and as single-wave workgroups for all others (a team's LDS stays allocated until its last wave
@@ -1468,9 +1468,9 @@ void egr_trace_alloc(egr_context *c) {
     egr_build_task_order(c);
 }
 
-// Team help of the next launch: what the caller set, or - automatic - on for a rank of a partition with fewer than two 8x8 tiles per wave slot (its launch
-// lasts as long as its heaviest tile; help takes 5-8 % off its iteration), off for everything else (a whole image gains 6 % / 3 % of its forward chain too,
-// but then the order of EXACT depth ties of bounce rays - 0.1 % of the pixels of a 1080p frame hold one - varies from run to run, as it does upstream).
+// Team help of the next launch: on (default: a whole image's forward chain -6 % / -3 %, an under-filled rank's iteration -7 %), off, or - value -1 - on only for
+// a rank of a partition with fewer than two 8x8 tiles per wave slot. With help the order of EXACT depth ties of bounce rays (0.1 % of the pixels of a 1080p frame
+// hold one) varies from run to run, as it does upstream with the PPLL's insertion order; nothing else does (trace.hip: teams; forward_task.inc: total transmittance).
 bool egr_team_help_on(const egr_context *c) {
     if (EGR_TEAM <= 1) return false;
     if (c->team_help >= 0) return c->team_help == 1;

@@ -108,7 +108,7 @@ class GaussianRaytracer:
             self.cuda_module.resize(n)
         self.rank, self.world_size = rank, world_size
         self.import_grads = True  # False: a fused host step (trainer.FusedTrainStep) imports the raytracer gradients itself
-        if team_help is not None:  # several waves on one heavy tile (egr_set_team_help; library default: automatic = under-filled ranks of a partition). Only the order of EXACT depth ties depends on it
+        if team_help is not None:  # several waves on one heavy tile (egr_set_team_help; library default: on). Only the order of EXACT depth ties of bounce rays depends on it
             self.cuda_module.set_team_help(bool(team_help))
         if world_size > 1:
             self.cuda_module.set_partition(rank, world_size)

@@ -219,9 +219,9 @@ int egr_set_rays_per_task(egr_context *ctx, int rays_per_task);
  * enter its list, never the set; that order reaches an output only where two candidates of a ray have EXACTLY the same distance (the depth
  * selection orders by (t, list index); the total transmittance is an fp64 product rounded once): without exact ties the images of a run with
  * help equal those of a run without bit for bit (tests/test_hip_parity.py), with them the tied hits may composite in another order from run to
- * run (deviation (a); upstream the order of tied hits is its PPLL's insertion order, which is timing too). 1 = on (whole image: -6 % /
- * -3 % forward chain), 0 = off, -1 = automatic (default): on for a rank of a partition with fewer than two 8x8 tiles per wave slot, off otherwise -
- * a whole-image launch stays reproducible bit for bit; also env EGR_TEAM_HELP (0 / 1) at creation. Returns 1 for other values. (1 also selects the backward chain's team build, which an under-filled rank of a partition gets in any
+ * run (deviation (a); upstream the order of tied hits is its PPLL's insertion order, which is timing too). 1 = on (default since
+ * round 5: whole image -6 % / -3 % forward chain), 0 = off (launches reproducible bit for bit), -1 = on only for a rank of a partition with fewer than
+ * two 8x8 tiles per wave slot; also env EGR_TEAM_HELP (0 / 1) at creation. Returns 1 for other values. (1 also selects the backward chain's team build, which an under-filled rank of a partition gets in any
  * case: its waves without tiles take batches of their team mates' bounce hits - gradients are atomic adds, no result depends on it.) */
 int egr_set_team_help(egr_context *ctx, int on);
 

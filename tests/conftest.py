@@ -9,10 +9,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PKG_NAME = "editable-gaussian-reflections_amd"
-# Team help (egr_set_team_help) is automatic by default: ON for under-filled ranks of a partition - and a test image is small enough to make every
-# partitioned tracer of this suite such a rank. With help the ORDER of exact depth ties of bounce rays depends on timing, and many tests assert
-# bit-level equalities between a partitioned and a whole-image tracer; so the suite pins help OFF at creation (read by egr_create) and the tests of the
-# help protocols switch it on explicitly (test_team_help_changes_the_list_order_only, test_team_help_does_not_drift_training, the two-rank bench).
+# Team help (egr_set_team_help) is ON by default, and with it the ORDER of exact depth ties of bounce rays depends on timing (as upstream, where it is the
+# PPLL's insertion order). Many tests assert bit-level equalities - a frame rendered twice, a partitioned against a whole-image tracer, strands, fuse_live -
+# so the suite pins help OFF at creation (read by egr_create) and the tests of the help protocols switch it on explicitly
+# (test_team_help_changes_the_list_order_only, test_team_help_does_not_drift_training, the two-rank bench); smoke() and bench.py run the default.
 os.environ.setdefault("EGR_TEAM_HELP", "0")
 
 
