@@ -67,6 +67,7 @@ def lib(path=None):
         L.egr_grad_delta_consumed.argtypes = [P]
         L.egr_debug_set_pixel_mask.argtypes = [P, P]
         L.egr_set_targets_chw.argtypes = [P, P, P, P, P, P, P, P]
+        L.egr_set_camera_from_dataset.argtypes = [P, P, P, C.c_float, C.c_float, C.c_float, P]
         L.egr_tile_owner.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.egr_tile_owner.restype = C.c_int
         L.egr_set_strands.argtypes = [P, C.c_int]

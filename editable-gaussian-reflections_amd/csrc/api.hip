@@ -10,6 +10,7 @@ void egr_copy_final_to_denoised(egr_context *c, hipStream_t s);
 void egr_denoise_atrous(egr_context *c, hipStream_t s); // denoise.hip
 void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s); // trace.hip
 void egr_upload_targets(egr_context *c, const float *const chw[6], hipStream_t s); // trace.hip
+void egr_set_camera_launch(egr_context *c, const float *R, const float *centre, float fov, float znear, float zfar, hipStream_t s); // trace.hip
 
 void egr_stamp_begin(egr_context *c, const char *name, hipStream_t s) {
     if (!c->timing) return;
@@ -208,6 +209,11 @@ int egr_raytrace(egr_context *c, int grads_enabled, void *stream) {
         egr_trace_launch(c, grads_enabled != 0, live_fresh, s);
         if (c->timing) EGR_HIP(hipEventRecord(c->ev_rt1, s)), c->have_rt = true;
     });
+}
+
+int egr_set_camera_from_dataset(egr_context *c, const float *rotation_c2w_dataset, const float *camera_center, float vertical_fov_radians, float znear, float zfar, void *stream) {
+    if (!c || !c->bound || !rotation_c2w_dataset || !camera_center) return 1;
+    return guarded(c, [&] { egr_set_camera_launch(c, rotation_c2w_dataset, camera_center, vertical_fov_radians, znear, zfar, (hipStream_t)stream); });
 }
 
 int egr_set_targets_chw(egr_context *c, const float *diffuse, const float *specular, const float *depth, const float *normal, const float *roughness, const float *f0, void *stream) {

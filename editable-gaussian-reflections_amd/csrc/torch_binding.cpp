@@ -418,6 +418,12 @@ struct Raytracer : torch::CustomClassHolder {
         pixel_mask = mask.contiguous();
         check(egr_debug_set_pixel_mask(ctx, pixel_mask.data_ptr<uint8_t>()), "debug_set_pixel_mask");
     }
+    // pose + scalars of a view in one launch (egr_set_camera_from_dataset): R = the dataset's c2w rotation [3,3], centre = camera_center [3], fp32 CUDA tensors
+    void set_camera(Tensor R, Tensor centre, double fov, double znear, double zfar) {
+        TORCH_CHECK(R.is_cuda() && centre.is_cuda() && R.numel() == 9 && centre.numel() == 3, "set_camera: CUDA tensors [3,3] and [3] expected");
+        Tensor r = R.to(torch::kFloat32).contiguous(), cc = centre.to(torch::kFloat32).contiguous();
+        check(egr_set_camera_from_dataset(ctx, r.data_ptr<float>(), cc.data_ptr<float>(), (float)fov, (float)znear, (float)zfar, current_stream()), "set_camera");
+    }
     // the six target images of a training view, channel-major ([C,H,W] contiguous fp32 CUDA tensors; an undefined / empty tensor = absent = zeros), written into
     // the framebuffer's pixel-major target buffers for this context's own tiles in one launch (egr_set_targets_chw)
     void set_targets_chw(c10::optional<Tensor> diffuse, c10::optional<Tensor> specular, c10::optional<Tensor> depth, c10::optional<Tensor> normal, c10::optional<Tensor> roughness,
@@ -532,6 +538,7 @@ struct Raytracer : torch::CustomClassHolder {
             .def("grad_delta_consumed", &Raytracer::grad_delta_consumed)
             .def("debug_set_pixel_mask", &Raytracer::debug_set_pixel_mask)
             .def("set_targets_chw", &Raytracer::set_targets_chw)
+            .def("set_camera", &Raytracer::set_camera)
             .def("set_exact_stats", &Raytracer::set_exact_stats)
             .def("set_strands", &Raytracer::set_strands)
             .def("set_team_help", &Raytracer::set_team_help)

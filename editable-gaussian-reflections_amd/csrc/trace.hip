@@ -1292,6 +1292,20 @@ __global__ void __launch_bounds__(EGR_WAVE) k_export_step_hits(DeviceView v, int
     }
 }
 
+// Camera upload: what gaussian_raytracer.py:94-100 does with ten tiny tensor kernels (R_blender = -R with column 0 negated back, three fill_ calls,
+// set_pose's three copies) as ONE: R = the dataset's camera-to-world rotation (row-major 3x3), centre = camera_center, both device pointers.
+__global__ void k_set_camera(egr_camera cam, const float *__restrict__ R, const float *__restrict__ centre, float fov, float znear, float zfar) {
+    const int t = threadIdx.x;
+    if (t < 9) {
+        const int r = t / 3, c = t % 3;
+        const float rb = c == 0 ? R[t] : -R[t]; // (-R)[:, 0] *= -1
+        const_cast<float *>(cam.rotation_c2w)[t] = rb;
+        const_cast<float *>(cam.rotation_w2c)[3 * c + r] = rb; // transpose
+    }
+    if (t < 3) const_cast<float *>(cam.origin)[t] = centre[t];
+    if (t == 0) *const_cast<float *>(cam.vertical_fov_radians) = fov, *const_cast<float *>(cam.znear) = znear, *const_cast<float *>(cam.zfar) = zfar;
+}
+
 // Target upload (the caller's six `buf.copy_(val.moveaxis(0, -1))` of gaussian_raytracer.py:109-137 as ONE launch): CHW images -> the framebuffer's HWC
 // target buffers, for the pixels of THIS rank's tiles only (a rank of an 8-way partition reads and writes an eighth of the 116 MB a whole
 // 1080p frame moves); a missing image writes zeros, like the reference's `buf.zero_()`.
@@ -1610,6 +1624,10 @@ void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s) {
     if (v.num_tasks) hipLaunchKernelGGL(k_export_step_hits, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev.p);
     EGR_HIP(hipMemcpyAsync(host_out, dev.p, bytes, hipMemcpyDeviceToHost, s));
     EGR_HIP(hipStreamSynchronize(s));
+}
+
+void egr_set_camera_launch(egr_context *c, const float *R, const float *centre, float fov, float znear, float zfar, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_camera, dim3(1), dim3(64), 0, s, c->cam, R, centre, fov, znear, zfar);
 }
 
 void egr_upload_targets(egr_context *c, const float *const chw[6], hipStream_t s) {

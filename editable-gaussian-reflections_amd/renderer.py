@@ -206,12 +206,8 @@ class GaussianRaytracer:
         assert eval_mode is None or eval_mode in self.EVAL_MODES, eval_mode
         with torch.no_grad():
             R = torch.from_numpy(viewpoint_camera.R).cuda().float() if isinstance(viewpoint_camera.R, np.ndarray) else viewpoint_camera.R.cuda()
-            R_c2w_blender = self.blender_rotation(R.clone())
-            camera = self.cuda_module.get_camera()
-            camera.znear.fill_(float(os.getenv("ZNEAR", znear)))
-            camera.zfar.fill_(float(os.getenv("ZFAR", zfar)))
-            camera.vertical_fov_radians.fill_(float(viewpoint_camera.FoVy))
-            camera.set_pose(viewpoint_camera.camera_center.contiguous(), R_c2w_blender.contiguous())
+            # gaussian_raytracer.py:94-100 (R_c2w_blender = blender_rotation(R); znear / zfar / fov fill_; set_pose(camera_center, R_c2w_blender)) as ONE launch
+            self.cuda_module.set_camera(R, viewpoint_camera.camera_center, float(viewpoint_camera.FoVy), float(os.getenv("ZNEAR", znear)), float(os.getenv("ZFAR", zfar)))
             self._export_param_values()
             framebuffer = self.cuda_module.get_framebuffer()
             # CHW -> HWC into framebuffer.target_*, zeros when absent (gaussian_raytracer.py:109-137: six copy_ / zero_ calls) - as ONE launch over the

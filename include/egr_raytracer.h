@@ -155,6 +155,13 @@ int egr_update_bvh_ex(egr_context *ctx, unsigned flags, void *hip_stream);
  * torch::autograd::GradMode::is_enabled() returned in the caller (metadata.h:29). Asynchronous. */
 int egr_raytrace(egr_context *ctx, int grads_enabled, void *hip_stream);
 
+/* Camera upload (replaces the caller's ten tiny tensor kernels of renderer/gaussian_raytracer.py:94-100, which stay valid): rotation_c2w_dataset =
+ * the dataset's camera-to-world rotation `viewpoint_camera.R` (row-major 3x3 fp32), camera_center = `viewpoint_camera.camera_center` (3 fp32), both DEVICE
+ * pointers. ONE launch writes the bound camera struct: rotation_c2w = -R with column 0 negated back (the reference's Blender convention), its transpose,
+ * the origin, and the three scalars. Asynchronous on the stream. */
+int egr_set_camera_from_dataset(egr_context *ctx, const float *rotation_c2w_dataset, const float *camera_center, float vertical_fov_radians, float znear,
+                                float zfar, void *hip_stream);
+
 /* Target upload (replaces the caller's six `framebuffer.target_*.copy_(image.moveaxis(0, -1))` of renderer/gaussian_raytracer.py:109-137, which
  * stay valid): device pointers to channel-major fp32 images ([3][H][W] diffuse, specular, normal, f0; [1][H][W] depth, roughness), NULL = the
  * target is absent and reads zero (the reference zeroes the buffer). ONE launch writes the framebuffer's pixel-major target buffers for the pixels
