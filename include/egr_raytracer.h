@@ -215,7 +215,7 @@ int egr_set_exact_stats(egr_context *ctx, int enable);
 int egr_set_strands(egr_context *ctx, int strands);
 
 /* Task shape (not in the reference): pixels one wave traces together. 64 = 8x8 (default), 32 = 8x4, 16 = 4x4; 0 = automatic (64, or
- * 32 for a rank of a partition with fewer than two 8x8 tiles per resident wave). Also settable at creation with env
+ * 32 for a rank of a partition with fewer than two 8x8 tiles per resident wave when team help is off). Also settable at creation with env
  * EGR_RAYS_PER_TASK. The ORDER of exactly tied hits of a bounce ray depends on the shape (deviation (a)); parity tests
  * that trace single macro tiles through egr_set_partition pin the shape of the run they compare with. Returns 1 for other values. */
 int egr_set_rays_per_task(egr_context *ctx, int rays_per_task);

@@ -8,7 +8,7 @@ is therefore relative to that noise (measured: help off vs help off 9.7k of 630k
 iterations, help on vs off 80k - the list order touches the last bit of every bounce ray's total transmittance, the atomics only the sums
 that nearly cancel; worst mean parameter difference 2.5e-4 against 1.4e-5 of a tensor's maximum; final renders 50.4 dB against 62.1 dB).
 So help is a perturbation of a training run of the kind a change of the task shape is, 18x the size of the run-to-run noise of the float
-atomics after 20 iterations - which is why it is OFF by default - and no bias: asserted are the measured levels with a margin (mean
+atomics after 20 iterations (still a last-bit perturbation of every launch: Adam with eps = 1e-15 is what amplifies it) - and no bias: asserted are the measured levels with a margin (mean
 difference <= 40x the twin's, renders >= 45 dB).
 Prints TEAMHELP_OK on rank 0."""
 import importlib
