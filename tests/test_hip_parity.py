@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from hip_common import GOLD, GRAD_KEYS, OUT_KEYS, cam_obj, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
+from hip_common import GOLD, GRAD_KEYS, OUT_KEYS, PKG, cam_obj, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
 
 
 # ------------------------------------------------------------------------------------------------ K1/K2
@@ -571,6 +571,39 @@ def test_tile_partition_sums_to_full_image(ren, orc, syn, monkeypatch, rays_per_
     for k in GRAD_KEYS:
         s = gparts[0][k] + gparts[1][k]
         assert np.abs(s - gfull[k]).max() / (np.abs(gfull[k]).max() + 1e-30) < 1e-3, k
+
+
+@pytest.mark.parametrize("size", [(80, 48), (37, 29)])
+def test_targets_upload_equals_the_references_per_buffer_copies(ren, orc, syn, size):
+    """`set_targets_chw` (one launch) against what the reference's caller does per buffer (`renderer.py:118-147`:
+    `framebuffer.target_x.copy_(image.moveaxis(0, -1))`, a missing image zeroes the buffer): whole image (16-B path when the pixel
+    count allows, scalar path for 37 x 29) and a rank of two (own tiles only, the other pixels keep what they held)."""
+    W, H = size
+    g = syn.make_scene(500, "trained", seed=3)
+    cam = syn.default_camera()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    chans = dict(diffuse=3, specular=3, depth=1, normal=3, roughness=1, f0=3)
+    imgs = {k: torch.rand(c, H, W, generator=gen).cuda() for k, c in chans.items()}
+    order = ["diffuse", "specular", "depth", "normal", "roughness", "f0"]
+    for world, missing in ((1, ()), (1, ("specular", "depth")), (2, ("f0",))):
+        rt, _ = make_pair(ren, orc, g, cam, W, H)
+        m = rt.cuda_module
+        fb = m.get_framebuffer()
+        if world > 1:
+            m.set_partition(0, world)
+        for k in order:
+            getattr(fb, "target_" + k).fill_(-7.0)
+        m.set_targets_chw(*[None if k in missing else imgs[k] for k in order])
+        torch.cuda.synchronize()
+        own = torch.ones(H, W, dtype=torch.bool)
+        if world > 1:
+            owner = importlib.import_module(PKG + ".parallel").tile_owner(W, H, world)  # [mty, mtx]
+            own = torch.from_numpy(np.repeat(np.repeat(owner == 0, 16, axis=0), 16, axis=1)[:H, :W].copy())
+        for k in order:
+            got = getattr(fb, "target_" + k).cpu().reshape(H, W, chans[k])
+            want = torch.zeros(H, W, chans[k]) if k in missing else imgs[k].cpu().moveaxis(0, -1)
+            assert torch.equal(got[own], want[own]), (size, world, k)
+            assert bool((got[~own] == -7.0).all()), (size, world, k)
 
 
 def test_per_launch_gradient_buffer_never_drops_a_launch(ren, orc, syn):
