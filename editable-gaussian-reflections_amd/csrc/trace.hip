@@ -54,6 +54,9 @@
 #ifndef EGR_LEAF_FILTER
 #define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
 #endif
+#ifndef EGR_LEAF_ORIGIN
+#define EGR_LEAF_ORIGIN 1 // primary tiles: a leaf's object-space origin W o + w computed once per leaf (one lane) and broadcast through LDS instead of per ray
+#endif
 #ifndef EGR_PSTK
 #define EGR_PSTK 512 // pair-stack entries kept in LDS
 #endif
@@ -120,25 +123,49 @@ EGR_DI f3 primary_direction(const DeviceView &v, int ix, int iy, bool jitter, ui
 #ifndef EGR_UNFUSED_CANDIDATE
 #define EGR_UNFUSED_CANDIDATE 0
 #endif
-#if EGR_UNFUSED_CANDIDATE
+// Which products of `a b + c d + e f` are fused is the compiler's choice PER CALL SITE (it differs between a uniform and a per-lane origin, and between
+// two instantiations of one template), while the forward's primary tiles, its pair walk - owner's and helpers' copies - and the backward's
+// recomputation must agree to the bit: the fusion is spelled out (the pattern the compiler applied to these expressions in rounds 1-5:
+// fma(e, f, fma(a, b, c d))) and the functions themselves are compiled without contraction.
 #pragma clang fp contract(off)
+EGR_DI float egr_dot3(float ax, float ay, float az, float bx, float by, float bz) {
+#if EGR_UNFUSED_CANDIDATE
+    return ax * bx + ay * by + az * bz;
+#else
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ax, bx, ay * by));
 #endif
+}
+EGR_DI float egr_madd(float a, float b, float c) { // a b + c
+#if EGR_UNFUSED_CANDIDATE
+    return a * b + c;
+#else
+    return __builtin_fmaf(a, b, c);
+#endif
+}
+// (the object-space ORIGIN of a ray is the same for every ray that leaves one point: primary tiles compute it once per leaf, forward_task.inc)
+EGR_DI f3 object_origin(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &o) {
+    f3 lo;
+    lo.x = egr_dot3(w0.x, w0.y, w0.z, o.x, o.y, o.z) + w0.w, lo.y = egr_dot3(w1.x, w1.y, w1.z, o.x, o.y, o.z) + w1.w, lo.z = egr_dot3(w2.x, w2.y, w2.z, o.x, o.y, o.z) + w2.w;
+    return lo;
+}
+EGR_DI void candidate_geometry_from(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &lo, const f3 &d, f3 &ld, f3 &dhat, float &t, f3 &u, bool &behind,
+                                    bool &outside) {
+    ld.x = egr_dot3(w0.x, w0.y, w0.z, d.x, d.y, d.z), ld.y = egr_dot3(w1.x, w1.y, w1.z, d.x, d.y, d.z), ld.z = egr_dot3(w2.x, w2.y, w2.z, d.x, d.y, d.z);
+    const float norm = sqrtf(egr_dot3(ld.x, ld.y, ld.z, ld.x, ld.y, ld.z)); // :41
+    const float inv = 1.0f / norm;
+    dhat.x = ld.x * inv, dhat.y = ld.y * inv, dhat.z = ld.z * inv;          // :42
+    const float tl = egr_dot3(-lo.x, -lo.y, -lo.z, dhat.x, dhat.y, dhat.z); // :43
+    t = tl / norm;                                                          // :44
+    u.x = egr_madd(tl, dhat.x, lo.x), u.y = egr_madd(tl, dhat.y, lo.y), u.z = egr_madd(tl, dhat.z, lo.z); // :45
+    behind = egr_dot3(lo.x, lo.y, lo.z, ld.x, ld.y, ld.z) > 0.0f;           // :36
+    outside = egr_dot3(u.x, u.y, u.z, u.x, u.y, u.z) > 1.0f;                // :48-49
+}
 EGR_DI void candidate_geometry(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &o, const f3 &d, f3 &lo, f3 &ld, f3 &dhat, float &t, f3 &u,
                                bool &behind, bool &outside) {
-    lo.x = w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, lo.y = w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w, lo.z = w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w;
-    ld.x = w0.x * d.x + w0.y * d.y + w0.z * d.z, ld.y = w1.x * d.x + w1.y * d.y + w1.z * d.z, ld.z = w2.x * d.x + w2.y * d.y + w2.z * d.z;
-    const float norm = sqrtf(ld.x * ld.x + ld.y * ld.y + ld.z * ld.z); // :41
-    const float inv = 1.0f / norm;
-    dhat.x = ld.x * inv, dhat.y = ld.y * inv, dhat.z = ld.z * inv;      // :42
-    const float tl = (-lo.x) * dhat.x + (-lo.y) * dhat.y + (-lo.z) * dhat.z; // :43
-    t = tl / norm;                                                        // :44
-    u.x = lo.x + tl * dhat.x, u.y = lo.y + tl * dhat.y, u.z = lo.z + tl * dhat.z; // :45
-    behind = lo.x * ld.x + lo.y * ld.y + lo.z * ld.z > 0.0f;             // :36
-    outside = u.x * u.x + u.y * u.y + u.z * u.z > 1.0f;                   // :48-49
+    lo = object_origin(w0, w1, w2, o);
+    candidate_geometry_from(w0, w1, w2, lo, d, ld, dhat, t, u, behind, outside);
 }
-#if EGR_UNFUSED_CANDIDATE
 #pragma clang fp contract(fast)
-#endif
 // Wave-uniform node fetch: constant address space + uniform index => one s_load_dwordx8 through the scalar cache
 // (the tree is read-only for the whole launch) instead of a 64-lane vector load.
 typedef float egr_v8f __attribute__((ext_vector_type(8)));
@@ -315,11 +342,16 @@ struct WalkStats { // diagnostic builds (EGR_TRAVERSAL_STATS, EGR_TASK_TIMES)
 // SEG0: the caller's copy of the loop only runs for segment 0 (the hot case: no runtime segment dispatch).
 template <bool CUBE, bool SEG0, class A2>
 EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plane, const f3 &o, const f3 &d, uint32_t prim, const float4 &w0, const float4 &w1,
-                          const float4 &w2, A2 a2src, float &t, float &alpha) {
+                          const float4 &w2, A2 a2src, float &t, float &alpha, const f3 *lo_pre = nullptr) {
     const float far_plane = fc.far_plane;
     f3 lo, ld, dhat, u;
     bool behind, outside;
-    candidate_geometry(w0, w1, w2, o, d, lo, ld, dhat, t, u, behind, outside); // :19-20, :36, :41-51
+    if (lo_pre != nullptr) { // (primary tiles: the object-space origin was computed once per leaf - the same expression, object_origin)
+        lo = *lo_pre;
+        candidate_geometry_from(w0, w1, w2, lo, d, ld, dhat, t, u, behind, outside);
+    } else {
+        candidate_geometry(w0, w1, w2, o, d, lo, ld, dhat, t, u, behind, outside); // :19-20, :36, :41-51
+    }
     if constexpr (CUBE) {
         // exact-statistics build: the tree bounds the instance cubes, one walk over [tmin,tmax] meets every instance OptiX
         // would invoke the intersection program for; the cube test is the oracle's (IEEE division)
@@ -343,11 +375,11 @@ EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plan
     if (step != 0 && t < fc.backfacing_max_dist) {  // :54-61 (world normal . object dir)
         const float4 n0 = fc.app[2 * prim], n1 = fc.app[2 * prim + 1]; // raw normal, record order (k_live)
         f3 gn = mk3(n0.w, n1.x, n1.y);
-        if (length(gn) > fc.backfacing_thr && dot(gn, dhat) > 0.0f) return 1;
+        if (sqrtf(egr_dot3(gn.x, gn.y, gn.z, gn.x, gn.y, gn.z)) > fc.backfacing_thr && egr_dot3(gn.x, gn.y, gn.z, dhat.x, dhat.y, dhat.z) > 0.0f) return 1;
     }
     const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
     f3 x = u * a2.w;                                          // :64
-    float gaussval = eval_gaussian_sq(dot(x, x), fc.exp_power); // :65
+    float gaussval = eval_gaussian_sq(egr_dot3(x.x, x.y, x.z, x.x, x.y, x.z), fc.exp_power); // :65 (spelled-out fusion: the owner's and a helper's copy of this test agree to the bit)
     alpha = EGR_MAX_ALPHA * gaussval * a2.z;                   // kernel.cu:14-16
     return 2;
 }
