@@ -54,6 +54,9 @@
 #ifndef EGR_LEAF_FILTER
 #define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
 #endif
+#ifndef EGR_LEAN_DIV
+#define EGR_LEAN_DIV 1 // candidate geometry: IEEE sqrt / division without the compiler's range scaling (same results in the normal range)
+#endif
 #ifndef EGR_LEAF_ORIGIN
 #define EGR_LEAF_ORIGIN 1 // primary tiles: a leaf's object-space origin W o + w computed once per leaf (one lane) and broadcast through LDS instead of per ray
 #endif
@@ -142,6 +145,31 @@ EGR_DI float egr_madd(float a, float b, float c) { // a b + c
     return __builtin_fmaf(a, b, c);
 #endif
 }
+// IEEE square root and division of the candidate geometry WITHOUT the range scaling the compiler's expansions carry (v_div_scale / v_div_fixup,
+// the 2^32 pre-scaling of a denormal radicand): the same correction steps on the same hardware approximations - the sequence the compiler emits
+// for `sqrtf(x)` and `a / b` with the scaling taken out, so the results are the correctly rounded ones whenever no intermediate leaves the normal
+// range (|W d| of a usable gaussian is within 1e-15 ... 1e15). 17 of the 75 instructions of a rejected candidate.
+#if defined(__HIP_DEVICE_COMPILE__) && !EGR_UNFUSED_CANDIDATE && EGR_LEAN_DIV
+EGR_DI float egr_sqrt_rn(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x); // within 1 ulp
+    const float sd = u2f(f2u(s) - 1u), su = u2f(f2u(s) + 1u);
+    const float t = __builtin_fmaf(-sd, s, x) <= 0.0f ? sd : s;
+    return __builtin_fmaf(-su, s, x) > 0.0f ? su : t;
+}
+EGR_DI float egr_rcp_refined(float b) { // the reciprocal both quotients below start from
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+}
+EGR_DI float egr_div_rn(float a, float b, float r) { // a / b, r = egr_rcp_refined(b)
+    const float q0 = a * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), r, q1);
+}
+#else
+EGR_DI float egr_sqrt_rn(float x) { return sqrtf(x); }
+EGR_DI float egr_rcp_refined(float) { return 0.0f; }
+EGR_DI float egr_div_rn(float a, float b, float) { return a / b; }
+#endif
 // (the object-space ORIGIN of a ray is the same for every ray that leaves one point: primary tiles compute it once per leaf, forward_task.inc)
 EGR_DI f3 object_origin(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &o) {
     f3 lo;
@@ -151,11 +179,12 @@ EGR_DI f3 object_origin(const float4 &w0, const float4 &w1, const float4 &w2, co
 EGR_DI void candidate_geometry_from(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &lo, const f3 &d, f3 &ld, f3 &dhat, float &t, f3 &u, bool &behind,
                                     bool &outside) {
     ld.x = egr_dot3(w0.x, w0.y, w0.z, d.x, d.y, d.z), ld.y = egr_dot3(w1.x, w1.y, w1.z, d.x, d.y, d.z), ld.z = egr_dot3(w2.x, w2.y, w2.z, d.x, d.y, d.z);
-    const float norm = sqrtf(egr_dot3(ld.x, ld.y, ld.z, ld.x, ld.y, ld.z)); // :41
-    const float inv = 1.0f / norm;
+    const float norm = egr_sqrt_rn(egr_dot3(ld.x, ld.y, ld.z, ld.x, ld.y, ld.z)); // :41
+    const float rr = egr_rcp_refined(norm);
+    const float inv = egr_div_rn(1.0f, norm, rr);
     dhat.x = ld.x * inv, dhat.y = ld.y * inv, dhat.z = ld.z * inv;          // :42
     const float tl = egr_dot3(-lo.x, -lo.y, -lo.z, dhat.x, dhat.y, dhat.z); // :43
-    t = tl / norm;                                                          // :44
+    t = egr_div_rn(tl, norm, rr);                                           // :44
     u.x = egr_madd(tl, dhat.x, lo.x), u.y = egr_madd(tl, dhat.y, lo.y), u.z = egr_madd(tl, dhat.z, lo.z); // :45
     behind = egr_dot3(lo.x, lo.y, lo.z, ld.x, ld.y, ld.z) > 0.0f;           // :36
     outside = egr_dot3(u.x, u.y, u.z, u.x, u.y, u.z) > 1.0f;                // :48-49
