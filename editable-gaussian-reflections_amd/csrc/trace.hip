@@ -170,6 +170,11 @@ EGR_DI float egr_sqrt_rn(float x) { return sqrtf(x); }
 EGR_DI float egr_rcp_refined(float) { return 0.0f; }
 EGR_DI float egr_div_rn(float a, float b, float) { return a / b; }
 #endif
+EGR_DI f3 egr_div3_rn(const f3 &a, const f3 &b, const f3 &r) { return mk3(egr_div_rn(a.x, b.x, r.x), egr_div_rn(a.y, b.y, r.y), egr_div_rn(a.z, b.z, r.z)); } // a / b per component, r = refined reciprocals of b
+EGR_DI float egr_gaussian_sq(float sq, float exp_power) { // eval_gaussian_sq (kernel.cu:8-12) with the division by the launch constant 2p spelled out: its reciprocal is loop-invariant
+    const float two_p = 2.0f * exp_power;
+    return expf(egr_div_rn(-pow_exp(sq, exp_power), two_p, egr_rcp_refined(two_p)));
+}
 // (the object-space ORIGIN of a ray is the same for every ray that leaves one point: primary tiles compute it once per leaf, forward_task.inc)
 EGR_DI f3 object_origin(const float4 &w0, const float4 &w1, const float4 &w2, const f3 &o) {
     f3 lo;
@@ -408,7 +413,7 @@ EGR_DI int test_candidate(const FwdConst &fc, int step, int seg, float near_plan
     }
     const float4 a2 = fetch_a2(a2src);                        // live quarter of the record, only now
     f3 x = u * a2.w;                                          // :64
-    float gaussval = eval_gaussian_sq(egr_dot3(x.x, x.y, x.z, x.x, x.y, x.z), fc.exp_power); // :65 (spelled-out fusion: the owner's and a helper's copy of this test agree to the bit)
+    float gaussval = egr_gaussian_sq(egr_dot3(x.x, x.y, x.z, x.x, x.y, x.z), fc.exp_power); // :65 (spelled-out fusion: the owner's and a helper's copy of this test agree to the bit)
     alpha = EGR_MAX_ALPHA * gaussval * a2.z;                   // kernel.cu:14-16
     return 2;
 }
@@ -1012,7 +1017,7 @@ template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float
     candidate_geometry(W0, W1, W2, ro, rd, lo, ld, dhat, t_unused, u, behind_unused, outside_unused);
     const f3 local_hit = u * scaling_factor;
     const float sq_norm = dot(local_hit, local_hit);
-    const float gaussval = eval_gaussian_sq(sq_norm, exp_power);
+    const float gaussval = egr_gaussian_sq(sq_norm, exp_power);
 
     float d_opacity = EGR_MAX_ALPHA * dL_dalpha * gaussval; // :151-152
     d_opacity = d_opacity * opacity * (1.0f - opacity);
@@ -1029,17 +1034,22 @@ template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float
     const f3 scaling = mk3(M0.w, M1.w, M2.w); // exp(scale), stored by k_instances
     const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
                        scaling.z * scaling_factor + eps_scale_grad);
-    const f3 rot_0 = mk3(M0.x, M0.y, M0.z) / den, rot_1 = mk3(M1.x, M1.y, M1.z) / den, rot_2 = mk3(M2.x, M2.y, M2.z) / den; // :178-180
+    // (nine quotients over three denominators, further down four over |q| and two reciprocals: each denominator's reciprocal is refined once and every
+    // quotient corrected from it - egr_div_rn, the results of `/` - instead of seventeen full expansions of a division)
+    const f3 rden = mk3(egr_rcp_refined(den.x), egr_rcp_refined(den.y), egr_rcp_refined(den.z));
+    const f3 rot_0 = egr_div3_rn(mk3(M0.x, M0.y, M0.z), den, rden), rot_1 = egr_div3_rn(mk3(M1.x, M1.y, M1.z), den, rden), rot_2 = egr_div3_rn(mk3(M2.x, M2.y, M2.z), den, rden); // :178-180
     const f3 d_scale = (dl2w0 * rot_0 + dl2w1 * rot_1 + dl2w2 * rot_2) * scaling; // :181-182
     const f3 dr0 = dl2w0 * scaling, dr1 = dl2w1 * scaling, dr2 = dl2w2 * scaling; // :185-187
-    const float qn = sqrtf(qu.x * qu.x + qu.y * qu.y + qu.z * qu.z + qu.w * qu.w);
-    const float r = qu.x / qn, x = qu.y / qn, y = qu.z / qn, z = qu.w / qn; // activations.cu:66-69
+    const float qn = egr_sqrt_rn(qu.x * qu.x + qu.y * qu.y + qu.z * qu.z + qu.w * qu.w);
+    const float rqn = egr_rcp_refined(qn);
+    const float r = egr_div_rn(qu.x, qn, rqn), x = egr_div_rn(qu.y, qn, rqn), y = egr_div_rn(qu.z, qn, rqn), z = egr_div_rn(qu.w, qn, rqn); // activations.cu:66-69
     const float dL_dr = 2.f * x * (dr2.y - dr1.z) + 2.f * y * (dr0.z - dr2.x) + 2.f * z * (dr1.x - dr0.y); // :194-205
     const float dL_dx = -4.f * x * (dr1.y + dr2.z) + 2.f * y * (dr0.y + dr1.x) + 2.f * z * (dr0.z + dr2.x) + 2.f * r * (dr2.y - dr1.z);
     const float dL_dy = 2.f * x * (dr0.y + dr1.x) - 4.f * y * (dr0.x + dr2.z) + 2.f * z * (dr1.z + dr2.y) + 2.f * r * (dr0.z - dr2.x);
     const float dL_dz = 2.f * x * (dr0.z + dr2.x) + 2.f * y * (dr1.z + dr2.y) - 4.f * z * (dr0.x + dr1.y) + 2.f * r * (dr1.x - dr0.y);
     const float dd = dL_dr * qu.x + dL_dx * qu.y + dL_dy * qu.z + dL_dz * qu.w; // activations.cu:71-73
-    const float inv3 = 1.0f / (qn * qn * qn), inv1 = 1.0f / qn;
+    const float qn3 = qn * qn * qn;
+    const float inv3 = egr_div_rn(1.0f, qn3, egr_rcp_refined(qn3)), inv1 = egr_div_rn(1.0f, qn, rqn);
 
     // :210-220 flush: into the LDS table when a slot is found within 8 probes, else straight to global
     const float d_rot0 = dd * -qu.x * inv3 + dL_dr * inv1, d_rot1 = dd * -qu.y * inv3 + dL_dx * inv1;
