@@ -35,8 +35,11 @@ EGR_DI void step_epilogue_lane(const DeviceView &v, int step, bool grads, int nu
     // ---- R4: forward_pass.cu:142-155 ----
     const float rem = T - full_T;
     const float normalization = fmaxf(1.0f - T, *v.cfg.eps_forward_normalization);
-    const f3u r_rgb = div_s(c_rgb, normalization), r_n = div_s(c_n, normalization), r_f0 = div_s(c_f0, normalization);
-    const float r_depth = c_depth / normalization, r_rough = c_rough / normalization;
+    // (sutil's float3 / float is a * (1 / s), utils/vec_math.h:330-333: ONE reciprocal for the three vectors, two true quotients for the scalars - all
+    // three from one refined reciprocal of the denominator, the results of `/`: egr_device.hpp)
+    const float rnorm = egr_rcp_refined(normalization), inv_norm = egr_div_rn(1.0f, normalization, rnorm);
+    const f3u r_rgb = c_rgb * inv_norm, r_n = c_n * inv_norm, r_f0 = c_f0 * inv_norm;
+    const float r_depth = egr_div_rn(c_depth, normalization, rnorm), r_rough = egr_div_rn(c_rough, normalization, rnorm);
     f3u o_rgb = c_rgb + rem * r_rgb;
     const f3u o_n = c_n + rem * r_n, o_f0 = c_f0 + rem * r_f0;
     const float o_depth = c_depth + rem * r_depth, o_rough = c_rough + rem * r_rough;

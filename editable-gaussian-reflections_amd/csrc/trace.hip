@@ -54,9 +54,6 @@
 #ifndef EGR_LEAF_FILTER
 #define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
 #endif
-#ifndef EGR_LEAN_DIV
-#define EGR_LEAN_DIV 1 // candidate geometry: IEEE sqrt / division without the compiler's range scaling (same results in the normal range)
-#endif
 #ifndef EGR_LEAF_ORIGIN
 #define EGR_LEAF_ORIGIN 1 // primary tiles: a leaf's object-space origin W o + w computed once per leaf (one lane) and broadcast through LDS instead of per ray
 #endif
@@ -145,31 +142,6 @@ EGR_DI float egr_madd(float a, float b, float c) { // a b + c
     return __builtin_fmaf(a, b, c);
 #endif
 }
-// IEEE square root and division of the candidate geometry WITHOUT the range scaling the compiler's expansions carry (v_div_scale / v_div_fixup,
-// the 2^32 pre-scaling of a denormal radicand): the same correction steps on the same hardware approximations - the sequence the compiler emits
-// for `sqrtf(x)` and `a / b` with the scaling taken out, so the results are the correctly rounded ones whenever no intermediate leaves the normal
-// range (|W d| of a usable gaussian is within 1e-15 ... 1e15). 17 of the 75 instructions of a rejected candidate.
-#if defined(__HIP_DEVICE_COMPILE__) && !EGR_UNFUSED_CANDIDATE && EGR_LEAN_DIV
-EGR_DI float egr_sqrt_rn(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x); // within 1 ulp
-    const float sd = u2f(f2u(s) - 1u), su = u2f(f2u(s) + 1u);
-    const float t = __builtin_fmaf(-sd, s, x) <= 0.0f ? sd : s;
-    return __builtin_fmaf(-su, s, x) > 0.0f ? su : t;
-}
-EGR_DI float egr_rcp_refined(float b) { // the reciprocal both quotients below start from
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    return __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
-}
-EGR_DI float egr_div_rn(float a, float b, float r) { // a / b, r = egr_rcp_refined(b)
-    const float q0 = a * r;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), r, q0);
-    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), r, q1);
-}
-#else
-EGR_DI float egr_sqrt_rn(float x) { return sqrtf(x); }
-EGR_DI float egr_rcp_refined(float) { return 0.0f; }
-EGR_DI float egr_div_rn(float a, float b, float) { return a / b; }
-#endif
 EGR_DI f3 egr_div3_rn(const f3 &a, const f3 &b, const f3 &r) { return mk3(egr_div_rn(a.x, b.x, r.x), egr_div_rn(a.y, b.y, r.y), egr_div_rn(a.z, b.z, r.z)); } // a / b per component, r = refined reciprocals of b
 EGR_DI float egr_gaussian_sq(float sq, float exp_power) { // eval_gaussian_sq (kernel.cu:8-12) with the division by the launch constant 2p spelled out: its reciprocal is loop-invariant
     const float two_p = 2.0f * exp_power;
