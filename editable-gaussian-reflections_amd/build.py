@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result"]
 if os.environ.get("EGR_GPOP"):
     HIP_FLAGS.append("-DEGR_GPOP=" + os.environ["EGR_GPOP"])
-for _k in ("EGR_FWD_WAVES", "EGR_PRIMARY_TABLE", "EGR_BWD_WAVES", "EGR_GT_SLOTS", "EGR_SAH_COLLAPSE", "EGR_PAIR_PRIMARY", "EGR_PSTK", "EGR_PIPELINE", "EGR_COMBINE_MASK", "EGR_BWD_COMPACT", "EGR_UNFUSED_CANDIDATE", "EGR_TEAM", "EGR_BOX", "EGR_DONATE_MIN", "EGR_ORDER_BUCKETS", "EGR_ORDER_SHIFT", "EGR_BWD_TEAM", "EGR_HOIST_BOUNCE", "EGR_EARLY_M", "EGR_FLUSH_WHEN_FULL", "EGR_LEAF_FILTER", "EGR_FPOP", "EGR_LEAF_ORIGIN", "EGR_KEYS_IL", "EGR_LEAN_DIV", "EGR_X1", "EGR_X2"):  # tuning experiments (tools/sweep.sh); X1 / X2 are scratch switches for one-off experiments in a working tree
+for _k in ("EGR_FWD_WAVES", "EGR_PRIMARY_TABLE", "EGR_BWD_WAVES", "EGR_GT_SLOTS", "EGR_SAH_COLLAPSE", "EGR_PAIR_PRIMARY", "EGR_PSTK", "EGR_PIPELINE", "EGR_COMBINE_MASK", "EGR_BWD_COMPACT", "EGR_UNFUSED_CANDIDATE", "EGR_TEAM", "EGR_BOX", "EGR_DONATE_MIN", "EGR_ORDER_BUCKETS", "EGR_ORDER_SHIFT", "EGR_BWD_TEAM", "EGR_HOIST_BOUNCE", "EGR_EARLY_M", "EGR_FLUSH_WHEN_FULL", "EGR_LEAF_FILTER", "EGR_FPOP", "EGR_LEAF_ORIGIN", "EGR_KEYS_IL", "EGR_VALS_IL", "EGR_LEAN_DIV", "EGR_X1", "EGR_X2"):  # tuning experiments (tools/sweep.sh); X1 / X2 are scratch switches for one-off experiments in a working tree
     if os.environ.get(_k):
         HIP_FLAGS.append("-D" + _k + "=" + os.environ[_k])
 if os.environ.get("EGR_EXTRA_FLAGS"):  # compiler-flag experiments, e.g. "-mllvm -amdgpu-sched-strategy=iterative-minreg"

@@ -54,6 +54,9 @@
 #ifndef EGR_LEAF_FILTER
 #define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
 #endif
+#ifndef EGR_VALS_IL
+#define EGR_VALS_IL 1 // (alpha, record) pairs in lane-interleaved groups of two
+#endif
 #ifndef EGR_KEYS_IL
 #define EGR_KEYS_IL 1 // candidate keys in lane-interleaved groups of four (a scan's 16-B loads are consecutive for the wave)
 #endif
@@ -419,9 +422,10 @@ EGR_DI void pair_eval_append(const DeviceView &v, const FwdConst &fc, WalkShared
         const size_t slot = (scratch0 + er) * v.cand_cap + at;
 #if EGR_KEYS_IL
         v.cand_keys[scratch0 * v.cand_cap + ((((size_t)(at >> 2) * EGR_WAVE + er) << 2) + (at & 3u))] = t; // (forward_decl.inc: EGR_KEY_AT of the owner's region)
-        v.cand_vals[slot] = make_float2(alpha, u2f(pidx));
+        v.cand_vals[slot] = make_float2(alpha, u2f(pidx)); // (a pair walk's lists are contiguous runs: forward_decl.inc)
 #else
-        v.cand_keys[slot] = t, v.cand_vals[slot] = make_float2(alpha, u2f(pidx));
+        v.cand_keys[slot] = t;
+        v.cand_vals[slot] = make_float2(alpha, u2f(pidx)); // (a pair walk's lists are contiguous runs: forward_decl.inc)
 #endif
     }
     if (__ballot(in_ext) != 0ull) { // rare: some list outgrew its run - it continues in ONE extension block per ray
