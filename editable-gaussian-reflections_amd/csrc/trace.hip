@@ -49,7 +49,7 @@
 #define EGR_PAIR_PRIMARY 0 // 1: primary rays walk pairwise too (0: one packet per tile)
 #endif
 #ifndef EGR_FPOP
-#define EGR_FPOP 2 // frustum walk: 8 x EGR_FPOP nodes per iteration (two interleaved same-box pairs: forward chain 3.80-3.87 against 3.92-3.95 ms dense-init; 3 and 4 no further)
+#define EGR_FPOP 2 // frustum walk: 8 x EGR_FPOP nodes per iteration (two interleaved same-box pairs: forward chain 3.80-3.87 against 3.92-3.95 ms dense-init; 3 and 4 no further - and with EGR_LEAF_ORIGIN the ray table holds the origins of at most 64 + 8 x 2 x 8 buffered leaves: a static_assert says so)
 #endif
 #ifndef EGR_LEAF_FILTER
 #define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
