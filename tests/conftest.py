@@ -10,9 +10,11 @@ if ROOT not in sys.path:
 
 PKG_NAME = "editable-gaussian-reflections_amd"
 # Team help (egr_set_team_help) is ON by default, and with it the ORDER of exact depth ties of bounce rays depends on timing (as upstream, where it is the
-# PPLL's insertion order). Many tests assert bit-level equalities - a frame rendered twice, a partitioned against a whole-image tracer, strands, fuse_live -
-# so the suite pins help OFF at creation (read by egr_create) and the tests of the help protocols switch it on explicitly
-# (test_team_help_changes_the_list_order_only, test_team_help_does_not_drift_training, the two-rank bench); smoke() and bench.py run the default.
+# PPLL's insertion order). Many tests assert bit-level equalities between TWO LAUNCHES - a frame rendered twice, a partitioned against a whole-image tracer,
+# strands, fuse_live - so tracers that are created without a `team_help` argument get help OFF (read by egr_create). Every test that holds the kernels
+# against the ORACLE with a tolerance runs in both modes (hip_common.BOTH_HELP_MODES; the at-size gradient check of BASELINE config C additionally as the
+# eight ranks of a partition, where help is most of the launch): the team builds k_forward_chain<.., 16> / k_backward_chain<4> that bench.py times are the
+# ones under test there. smoke() and bench.py run the library default.
 os.environ.setdefault("EGR_TEAM_HELP", "0")
 
 

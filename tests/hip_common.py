@@ -13,6 +13,11 @@ OUT_KEYS = ["output_rgb", "output_depth", "output_normal", "output_f0", "output_
             "output_total_transmittance", "output_ray_origin", "output_ray_direction", "output_final"]
 GRAD_KEYS = ["dL_drgb", "dL_dnormal", "dL_df0", "dL_droughness", "dL_dopacity", "dL_dscale", "dL_dmean", "dL_drotation", "total_weight"]
 
+# The suite pins team help OFF at creation (conftest.py: many tests assert bit equality between two launches), but the kernels the product ships and bench.py
+# times are the TEAM builds (k_forward_chain<.., 16>, k_backward_chain<4>: egr_set_team_help(1), the library default). Every test that compares with the ORACLE
+# with a tolerance runs twice: help off (single-wave workgroups) and the product default (teams; help across the CU's waves and, round 6, across the GPU).
+BOTH_HELP_MODES = pytest.mark.parametrize("team_help", [False, True], ids=["help_off", "product_default_help_on"])
+
 
 @pytest.fixture(scope="module")
 def ren():

@@ -18,7 +18,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from hip_common import GOLD, GRAD_KEYS, OUT_KEYS, PKG, cam_obj, generic_targets, grads_vs_oracle_listing_flipped_pixels, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
+from hip_common import BOTH_HELP_MODES, GOLD, GRAD_KEYS, OUT_KEYS, PKG, cam_obj, generic_targets, grads_vs_oracle_listing_flipped_pixels, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
 
 
 # ------------------------------------------------------------------------------------------------ config 1
@@ -56,13 +56,14 @@ def test_config_a_model_directory_renders_the_golden_image(ren, syn):
 
 
 # ------------------------------------------------------------------------------------------------ config 2
-def test_config_b_100k_1080p_forward_only(ren, orc, syn):
+@BOTH_HELP_MODES
+def test_config_b_100k_1080p_forward_only(ren, orc, syn, team_help):
     """BASELINE config 2: synthetic dense-init cloud, N = 100k, 1920x1080, forward only under no_grad with no BVH update between
     frames (measure_fps.py:27-52). Size-independent properties at full size + the oracle on the same scene at low resolution."""
     W, H, N = 1920, 1080, 100_000
     g = syn.make_scene(N, "init", seed=0)
     cam = syn.default_camera()
-    rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=400_000_000, ppll_backward_size=1_000_000)
+    rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=400_000_000, ppll_backward_size=1_000_000, team_help=team_help)
     m = rt.cuda_module
     fb = m.get_framebuffer()
     with torch.no_grad():
@@ -80,7 +81,10 @@ def test_config_b_100k_1080p_forward_only(ren, orc, syn):
     m.get_metadata().total_num_calls.sub_(1)
     with torch.no_grad():
         rt(cam_obj(ren, cam))
-    assert torch.equal(a, fb.output_final)  # idempotent: same call counter, bit-identical image
+    if team_help:  # with help only the ORDER of exactly tied depths of bounce rays depends on timing: a 1080p frame holds such a tie in ~ 0.1 % of its bounce rays
+        assert float((a != fb.output_final).any(-1).float().mean()) < 2e-3
+    else:
+        assert torch.equal(a, fb.output_final)  # idempotent: same call counter, bit-identical image
     report("config_b", rays=list(c[0:3]), evaluated_per_ray=[round(c[3 + i] / max(c[i], 1), 1) for i in range(3)],
            composited_per_ray=[round(c[6 + i] / max(c[i], 1), 1) for i in range(3)])
     # the same frame against the oracle AT THE CONFIG'S OWN SIZE: the pixels of 48 macro tiles (pixel mask on both sides), reference defaults
@@ -113,10 +117,10 @@ def test_config_b_100k_1080p_forward_only(ren, orc, syn):
             lv[f"{key}[{s_}]"] = round(float(psnr(out[key][s_][crop], ref[key][s_][crop])), 1)
     lv["output_final"] = round(float(psnr(out["output_final"][0][crop], ref["output_final"][0][crop])), 1)
     hits_differ = int((m.get_stats().num_accumulated_per_pixel.cpu().numpy().reshape(H, W)[crop] != ref["num_accumulated"][crop]).sum())
-    report("config_b_crop_at_size_vs_oracle", pixels=int(crop.sum()), worst=min(lv.values()), pixels_with_other_last_step_hit_count=hits_differ, **lv)
+    report(f"config_b_crop_at_size_vs_oracle[{'help_on' if team_help else 'help_off'}]", pixels=int(crop.sum()), worst=min(lv.values()), pixels_with_other_last_step_hit_count=hits_differ, **lv)
     assert min(lv.values()) >= 50.0, lv
     Ws, Hs = 160, 90
-    rt2, o = make_pair(ren, orc, g, cam, Ws, Hs, cfg=dict(jitter_primary_rays=0), fwd=100_000_000, bwd=1_000_000)
+    rt2, o = make_pair(ren, orc, g, cam, Ws, Hs, cfg=dict(jitter_primary_rays=0), fwd=100_000_000, bwd=1_000_000, team_help=team_help)
     with torch.no_grad():
         rt2(cam_obj(ren, cam))
     ref = o.raytrace(False)
@@ -173,8 +177,9 @@ CROP_BARS = {("init", 2): dict(clean=0.97, psnr_clean=85.0, psnr_all=70.0, err_a
              ("trained", 0): dict(clean=0.985, psnr_clean=100.0, psnr_all=85.0, err_all=3e-3, differing=12)}    # measured 0.993, 117.6 dB, 96.0 dB, 1.8e-3, 5
 
 
+@pytest.mark.parametrize("mode", ["help_off", "product_default_help_on", "help_on_eight_ranks_summed"])
 @pytest.mark.parametrize("variant,bounces", [("init", 2), ("trained", 2), ("trained", 0)])
-def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounces):
+def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounces, mode):
     """BASELINE config 3 as written: 1M gaussians, 1920x1080, forward + backward, REFERENCE DEFAULTS (jitter on, two bounces,
     training loss weights), "grad check vs ref" AT THE CONFIG'S OWN SIZE. Both sides trace the pixels of 48 macro tiles of the
     full-size frame - same gaussians, same camera, same rays as the whole image - through a PIXEL MASK (oracle: set_pixel_mask; HIP:
@@ -199,7 +204,12 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
         oracle's max-abs;
       * on ALL traced pixels: >= 35 dB, gradients < 2e-2, and no more differing pixels than measured + margin.
     The targets are moved off the scene's own wall values (normal, depth, roughness, f0): where an opaque wall renders exactly its
-    target, sign(output - target) hangs on the last bit on both sides."""
+    target, sign(output - target) hangs on the last bit on both sides.
+
+    `mode`: the kernels under test. "help_off" = single-wave workgroups (k_forward_chain<.., 1>, k_backward_chain<1>); "product_default_help_on" = what the
+    library ships and bench.py times (teams: k_forward_chain<.., 16>, k_backward_chain<4>, waves without tiles walk other tiles' pairs - in this masked launch
+    most waves have none, so help is the rule); "help_on_eight_ranks_summed" = the same crop traced as the EIGHT ranks of an 8-way partition one after the
+    other (egr_set_partition(r, 8): every rank's launch is under-filled, help is most of it), images tiled together and gradients summed - the same bars."""
     W, H, N = 1920, 1080, 1_000_000
     par = importlib.import_module(PKG + ".parallel")
     bars = CROP_BARS[(variant, bounces)]
@@ -208,7 +218,8 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
     tg = generic_targets(syn, W, H)
     tg["normal"] = tg["normal"] + np.float32([0.11, -0.07, 0.05])
     tg["depth"] = tg["depth"] + np.float32(0.37)
-    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(num_bounces=bounces), fwd=400_000_000, bwd=300_000_000)  # reference defaults + the training loss weights
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(num_bounces=bounces), fwd=400_000_000, bwd=300_000_000, team_help=(mode != "help_off"))  # reference defaults + the training loss weights
+    parts = [(r, 8) for r in range(8)] if mode == "help_on_eight_ranks_summed" else [(0, 1)]
     o64 = orc.Oracle(W, H, double=True)
     o64.set_camera(cam["origin"], cam["c2w"], cam["fov"])
     o64.set_gaussians(g)
@@ -229,19 +240,30 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
             if images:
                 for name in OUT_KEYS:
                     getattr(m.get_framebuffer(), name).zero_()
-                m.get_metadata().total_num_calls.fill_(K - 1)
-                with torch.no_grad():
-                    rt(camt)
-                assert m.get_counters()[0] == int(mask.sum())
+                rays = 0
+                for r, w in parts:  # (a rank of a partition writes the pixels of its own tiles: the eight launches tile the image together)
+                    m.set_partition(r, w)
+                    m.get_metadata().total_num_calls.fill_(K - 1)
+                    with torch.no_grad():
+                        rt(camt)
+                    rays += m.get_counters()[0]
+                assert rays == int(mask.sum())
                 img = hip_outputs(rt)
             rt.zero_grad()
             m.get_gaussians().total_weight.zero_()
-            m.get_metadata().total_num_calls.fill_(K - 1)
-            ren.render(camt, rt)
-            assert m.get_counters()[11] == 0 and m.get_counters()[0] == int(mask.sum())
-            return img, hip_grads(rt), m.debug_step_hits().numpy()
+            rays, hits = 0, 0
+            for r, w in parts:  # (grad launches ADD to the gradient tensors, like the reference's atomicAdds: eight ranks sum up)
+                m.set_partition(r, w)
+                m.get_metadata().total_num_calls.fill_(K - 1)
+                ren.render(camt, rt)
+                assert m.get_counters()[11] == 0
+                rays += m.get_counters()[0]
+                hits = hits + m.debug_step_hits().numpy()  # (pixels outside the rank's tiles report 0)
+            assert rays == int(mask.sum())
+            return img, hip_grads(rt), hits
         finally:
             m.debug_set_pixel_mask(torch.empty(0, dtype=torch.uint8))
+            m.set_partition(0, 1)
 
     def oracle_on(oo, mask, images=False):
         oo.set_pixel_mask(mask)
@@ -295,7 +317,7 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
     err_clean = errors(grad_hc, ref_c, ref)
     fmt = lambda d: {k: f"{v:.1e}" for k, v in d.items()}
     share = float(clean.sum()) / float(crop.sum())
-    report(f"config_c_crop_{variant}_bounces{bounces}", tiles=len(CROP_TILES), pixels=int(crop.sum()), composited=ref["num_composited_per_step"].sum(axis=(1, 2)).tolist(),
+    report(f"config_c_crop_{variant}_bounces{bounces}[{mode}]", tiles=len(CROP_TILES), pixels=int(crop.sum()), composited=ref["num_composited_per_step"].sum(axis=(1, 2)).tolist(),
            clean_pixels=int(clean.sum()), clean_share=round(share, 4), pixels_with_other_hit_counts=int(differing.sum()), pixels_with_a_4ulp_depth_tie=int(near_tie.sum()),
            differing_with_a_decision_within_1e3=int((differing & thin).sum()), differing_where_fp32_and_fp64_oracle_differ_too=int((differing & differing_oracles).sum()),
            differing_on_the_primary_step=int(differing0.sum()), primary_step_unexplained=int(unexplained.sum()), pixels_with_outputs_off_by_1e3=int(off.sum()), pixels_where_fp32_and_fp64_oracle_differ_in_hit_counts=int(differing_oracles.sum()),

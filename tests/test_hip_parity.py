@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from hip_common import GOLD, GRAD_KEYS, OUT_KEYS, PKG, cam_obj, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
+from hip_common import BOTH_HELP_MODES, GOLD, GRAD_KEYS, OUT_KEYS, PKG, cam_obj, hip_grads, hip_outputs, make_pair, mismatch_list, psnr, ren, report, run_grad  # noqa: F401
 
 
 # ------------------------------------------------------------------------------------------------ K1/K2
@@ -227,11 +227,12 @@ def test_exact_stats_mode_counts_reference_invocations(ren, orc, syn, variant, b
         assert np.abs(ge[k] - gd[k]).max() / (np.abs(gd[k]).max() + 1e-30) < 1e-4, k
 
 
-def test_forward_parity_with_bounces_and_jitter(ren, orc, syn):
+@BOTH_HELP_MODES
+def test_forward_parity_with_bounces_and_jitter(ren, orc, syn, team_help):
     W, H = 96, 64
     g = syn.make_scene(4000, "trained", seed=12)
     cam = syn.default_camera()
-    rt, o = make_pair(ren, orc, g, cam, W, H)  # reference defaults: jitter on, 2 bounces
+    rt, o = make_pair(ren, orc, g, cam, W, H, team_help=team_help)  # reference defaults: jitter on, 2 bounces
     for call in range(2):  # a different jitter pattern per call (seed = tea4(pixel, total_num_calls))
         with torch.no_grad():
             rt(cam_obj(ren, cam))
@@ -252,14 +253,15 @@ def test_forward_parity_with_bounces_and_jitter(ren, orc, syn):
         assert (ref["effective_steps"] > 1).mean() > 0.5  # the bounce steps were really exercised
 
 
-def test_golden_fixture(ren, orc, syn):
+@BOTH_HELP_MODES
+def test_golden_fixture(ren, orc, syn, team_help):
     z = np.load(os.path.join(GOLD, "scene_2k_64.npz"))
     W, H = int(z["W"]), int(z["H"])
     g = {k[2:]: z[k] for k in z.files if k.startswith("g_")}
     cam = {k[4:]: z[k] for k in z.files if k.startswith("cam_")}
     tg = {k[3:]: z[k] for k in z.files if k.startswith("tg_")}
     pc = ren.GaussianParams(g)
-    rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=8_000_000, ppll_backward_size=8_000_000)
+    rt = ren.GaussianRaytracer(pc, W, H, ppll_forward_size=8_000_000, ppll_backward_size=8_000_000, team_help=team_help)
     with torch.no_grad():
         rt(cam_obj(ren, cam))
     out = hip_outputs(rt)
@@ -278,13 +280,14 @@ def test_golden_fixture(ren, orc, syn):
 
 
 # ------------------------------------------------------------------------------------------------ backward
+@BOTH_HELP_MODES
 @pytest.mark.parametrize("bounces", [0, 2])
-def test_backward_parity(ren, orc, syn, bounces):
+def test_backward_parity(ren, orc, syn, bounces, team_help):
     W, H = 80, 48
     g = syn.make_scene(3000, "trained", seed=21)
     cam = syn.default_camera()
     tg = syn.make_targets(W, H)
-    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=bounces))
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=bounces), team_help=team_help)
     run_grad(ren, rt, cam_obj(ren, cam, tg))
     ref = o.raytrace(True, targets=tg)
     gr = hip_grads(rt)
@@ -295,7 +298,8 @@ def test_backward_parity(ren, orc, syn, bounces):
     assert rt.cuda_module.get_counters()[11] == 0
 
 
-def test_backward_parity_long_bounce_chains(ren, orc, syn):
+@BOTH_HELP_MODES
+def test_backward_parity_long_bounce_chains(ren, orc, syn, team_help):
     """Bounce rays through a translucent cloud composite 20+ hits: their backward chains span several arena blocks per bounce step, which
     the two-pass bounce backward (suffix sums per ray, geometry per hit; backward_task.inc) walks in chunks of four rows. Surfaces are made
     specular enough for the bounces to happen at all (a dense-init cloud's accumulated normal is too short for most rays)."""
@@ -306,7 +310,7 @@ def test_backward_parity_long_bounce_chains(ren, orc, syn):
     g["opacity"] = np.full_like(g["opacity"], np.log(0.35 / 0.65)).astype(np.float32)  # sigmoid^-1(0.35): long lists AND a usable normal
     cam = syn.default_camera()
     tg = generic_targets(syn, W, H)
-    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=2))
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0, num_bounces=2), team_help=team_help)
     grads_vs_oracle_listing_flipped_pixels(ren, rt, o, cam_obj(ren, cam, tg), tg, W, H, "long_bounce_chains_grads")
     hits = rt.cuda_module.debug_step_hits().numpy()  # [3,H,W] of the last grad launch
     report("long_bounce_chains", max_hits_per_step=[int(hits[s].max()) for s in range(3)], bounce_rays=int((hits[1] > 0).sum()))
@@ -501,14 +505,15 @@ def test_capacity_overflow_is_flagged_not_silent(ren, orc, syn):
     assert status & 2, "hit-arena overflow must be reported"  # upstream writes out of bounds here (per_pixel_linked_list.h:30-42)
 
 
-def test_candidate_lists_longer_than_capacity_continue_in_extension_blocks(ren, orc, syn):
+@BOTH_HELP_MODES
+def test_candidate_lists_longer_than_capacity_continue_in_extension_blocks(ren, orc, syn, team_help):
     """ppll_forward_size so small that a ray's own run holds 64 candidates: longer lists spill into extension blocks (the
     reference's pool is global: a single ray may use any number of entries) and the images / gradients still match."""
     W, H = 96, 64
     g = syn.make_scene(6000, "init", seed=3)  # opacity 0.1: long candidate lists
     cam = syn.default_camera()
     tg = syn.make_targets(W, H)
-    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0), fwd=1000, bwd=50_000_000)
+    rt, o = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0), fwd=1000, bwd=50_000_000, team_help=team_help)
     with torch.no_grad():
         rt(cam_obj(ren, cam))
     c = rt.cuda_module.get_counters()
@@ -520,7 +525,7 @@ def test_candidate_lists_longer_than_capacity_continue_in_extension_blocks(ren, 
     for k in ("output_rgb", "output_final", "output_total_transmittance"):
         assert psnr(out[k], ref[k]) > 80, k
     # gradients: identical (up to float-atomic order) to a run whose lists fit their own runs
-    big, _ = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0), fwd=50_000_000, bwd=50_000_000)
+    big, _ = make_pair(ren, orc, g, cam, W, H, cfg=dict(jitter_primary_rays=0), fwd=50_000_000, bwd=50_000_000, team_help=team_help)
     for r in (rt, big):
         r.cuda_module.get_metadata().total_num_calls.zero_()
         run_grad(ren, r, cam_obj(ren, cam, tg))
