@@ -9,6 +9,7 @@
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s);
 void egr_denoise_atrous(egr_context *c, hipStream_t s); // denoise.hip
 void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s); // trace.hip
+void egr_export_hit_hash(egr_context *c, uint64_t *host_out, hipStream_t s); // trace.hip
 void egr_upload_targets(egr_context *c, const float *const chw[6], hipStream_t s); // trace.hip
 void egr_set_camera_launch(egr_context *c, const float *R, const float *centre, float fov, float znear, float zfar, hipStream_t s); // trace.hip
 
@@ -349,6 +350,11 @@ int egr_debug_set_pixel_mask(egr_context *c, const uint8_t *device_mask) {
 int egr_debug_get_step_hits(egr_context *c, int32_t *host_out, void *stream) {
     if (!c || !host_out || require_ready(c, false)) return 1;
     return guarded(c, [&] { egr_export_step_hits(c, host_out, (hipStream_t)stream); });
+}
+
+int egr_debug_get_hit_sequence_hash(egr_context *c, uint64_t *host_out, void *stream) {
+    if (!c || !host_out || require_ready(c, false)) return 1;
+    return guarded(c, [&] { egr_export_hit_hash(c, host_out, (hipStream_t)stream); });
 }
 
 int egr_debug_check_bvh(egr_context *c, void *stream) {

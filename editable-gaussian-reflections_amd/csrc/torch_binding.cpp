@@ -473,6 +473,11 @@ struct Raytracer : torch::CustomClassHolder {
         check(egr_debug_get_step_hits(ctx, t.data_ptr<int32_t>(), current_stream()), "debug_step_hits");
         return t;
     }
+    Tensor debug_hit_sequence_hash() { // [3,H,W] int64 (the bits of the uint64 hashes) on the host: ordered composited gaussian ids per pixel and step of the last grad launch
+        Tensor t = torch::zeros({EGR_NUM_STEPS, height, width}, torch::kInt64);
+        check(egr_debug_get_hit_sequence_hash(ctx, reinterpret_cast<uint64_t *>(t.data_ptr<int64_t>()), current_stream()), "debug_hit_sequence_hash");
+        return t;
+    }
     int64_t check_bvh() { return egr_debug_check_bvh(ctx, current_stream()); }
     std::string last_error() { return egr_last_error(ctx); }
     std::vector<Tensor> debug_instances() {
@@ -553,7 +558,8 @@ struct Raytracer : torch::CustomClassHolder {
             .def("check_bvh", &Raytracer::check_bvh)
             .def("last_error", &Raytracer::last_error)
             .def("debug_instances", &Raytracer::debug_instances)
-            .def("debug_step_hits", &Raytracer::debug_step_hits);
+            .def("debug_step_hits", &Raytracer::debug_step_hits)
+            .def("debug_hit_sequence_hash", &Raytracer::debug_hit_sequence_hash);
     }
 };
 

@@ -1347,6 +1347,33 @@ __global__ void __launch_bounds__(EGR_WAVE) k_export_step_hits(DeviceView v, int
     }
 }
 
+// Diagnostic export (egr_debug_get_hit_sequence_hash): per pixel and step a hash of the ORDERED sequence of gaussian ids the last GRAD launch composited - the
+// polynomial sum_i (id_i + 1) B^i mod 2^64 over the composite index i, evaluated back to front (Horner) along the step's arena chain, which is the order the
+// backward walks; the CPU oracle evaluates the same sum front to back (oracle/egr_oracle.cpp: Outputs::hit_sequence_hash). Equal hashes = the same hits in the same order.
+__global__ void __launch_bounds__(EGR_WAVE) k_export_hit_hash(DeviceView v, unsigned long long *__restrict__ out) {
+    const int lane = threadIdx.x;
+    constexpr unsigned long long B = 0x9E3779B97F4A7C15ull;
+    for (uint32_t task = blockIdx.x; task < v.num_tasks; task += gridDim.x) {
+        const TaskGeom tg = task_geom(v, task, lane);
+        const StateRef S = state_of(v, task, lane);
+        const uint32_t steps = tg.inside ? f2u(S.ld(F_STEPS)) : 0u;
+        for (int s = 0; s < EGR_NSTEPS; s++) {
+            uint32_t blk = v.task_last_block[(size_t)s * v.num_tasks + task];
+            const uint32_t nhits = (tg.inside && (uint32_t)s < steps && blk != 0xFFFFFFFFu) ? f2u(S.ld(SF(s, S_NHITS))) : 0u;
+            const uint32_t max_hits = wave_max_u32(nhits);
+            unsigned long long h = 0ull;
+            const uint32_t nblocks = (max_hits + EGR_HIT_BLOCK_ROWS - 1) / EGR_HIT_BLOCK_ROWS;
+            for (uint32_t b = nblocks; b-- > 0 && blk != 0xFFFFFFFFu;) {
+                const float4 *rows = v.hit_arena + (size_t)blk * (EGR_HIT_BLOCK_ROWS + 1) * EGR_WAVE;
+                for (int row = EGR_HIT_BLOCK_ROWS - 1; row >= 0; row--)
+                    if (b * EGR_HIT_BLOCK_ROWS + (uint32_t)row < nhits) h = h * B + (unsigned long long)v.gid_of_pos[f2u(rows[(size_t)(1 + row) * EGR_WAVE + lane].x)] + 1ull;
+                blk = f2u(rows[0].x); // the block before this one (header row, lane 0's word)
+            }
+            if (tg.inside) out[(size_t)s * v.num_pixels + tg.pixel_id] = h;
+        }
+    }
+}
+
 // Camera upload: what gaussian_raytracer.py:94-100 does with ten tiny tensor kernels (R_blender = -R with column 0 negated back, three fill_ calls,
 // set_pose's three copies) as ONE: R = the dataset's camera-to-world rotation (row-major 3x3), centre = camera_center, both device pointers.
 __global__ void k_set_camera(egr_camera cam, const float *__restrict__ R, const float *__restrict__ centre, float fov, float znear, float zfar) {
@@ -1706,6 +1733,20 @@ void egr_export_step_hits(egr_context *c, int32_t *host_out, hipStream_t s) {
     EGR_HIP(hipMalloc((void **)&dev.p, bytes));
     EGR_HIP(hipMemsetAsync(dev.p, 0, bytes, s));
     if (v.num_tasks) hipLaunchKernelGGL(k_export_step_hits, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev.p);
+    EGR_HIP(hipMemcpyAsync(host_out, dev.p, bytes, hipMemcpyDeviceToHost, s));
+    EGR_HIP(hipStreamSynchronize(s));
+}
+
+void egr_export_hit_hash(egr_context *c, uint64_t *host_out, hipStream_t s) {
+    DeviceView v = egr_make_view(c);
+    const size_t bytes = (size_t)EGR_NSTEPS * v.num_pixels * sizeof(uint64_t);
+    struct DevBuf {
+        unsigned long long *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } dev;
+    EGR_HIP(hipMalloc((void **)&dev.p, bytes));
+    EGR_HIP(hipMemsetAsync(dev.p, 0, bytes, s));
+    if (v.num_tasks) hipLaunchKernelGGL(k_export_hit_hash, dim3(std::min(v.num_tasks, 65535u)), dim3(EGR_WAVE), 0, s, v, dev.p);
     EGR_HIP(hipMemcpyAsync(host_out, dev.p, bytes, hipMemcpyDeviceToHost, s));
     EGR_HIP(hipStreamSynchronize(s));
 }

@@ -256,6 +256,11 @@ int egr_debug_get_instances(egr_context *ctx, float *M, float *W, float *aabb, v
  * int32 [EGR_NUM_STEPS][H*W], host pointer; pixels outside this context's partition read 0. Parity tests use it to LIST the
  * pixels whose bounce rays met a different number of hits than the CPU oracle's. Synchronises. */
 int egr_debug_get_step_hits(egr_context *ctx, int32_t *host_out, void *hip_stream);
+/* The ORDERED sequence of gaussians every pixel composited on every step of the last egr_raytrace with grads_enabled, as a hash: host_out = uint64
+ * [EGR_NUM_STEPS][H*W] (host pointer), sum_i (id_i + 1) B^i mod 2^64 over the composite index i (front to back), B = 0x9E3779B97F4A7C15; 0 = no hit, and for
+ * pixels outside this context's partition. The CPU oracle reports the same number (oracle/egr_oracle.cpp: Outputs::hit_sequence_hash): a pixel composited the
+ * same hits in the same order on both sides iff the hashes agree - the definition of a "clean" pixel in the at-size gradient check. Synchronises. */
+int egr_debug_get_hit_sequence_hash(egr_context *ctx, uint64_t *host_out, void *hip_stream);
 /* Pixel mask for parity tests: device_mask = uint8 [H*W] in DEVICE memory (caller-owned, must outlive the launches that use it), or NULL
  * to clear. A pixel whose mask byte is 0 is treated like a pixel outside the image by every kernel of a launch: no ray, no outputs written,
  * no statistics, no gradient contribution. The CPU oracle has the same hook (orc_set_pixel_mask), so both sides can trace exactly the pixels

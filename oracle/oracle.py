@@ -61,7 +61,7 @@ _OUT_GRAD = ["dL_drgb", "dL_dnormal", "dL_df0", "dL_droughness", "dL_dopacity", 
              "total_weight"]
 
 
-_OUT_DIAG = ["num_bounce_near_ties", "decision_margin"]  # (after num_depth_ties in the C struct)
+_OUT_DIAG = ["num_bounce_near_ties", "hit_sequence_hash", "decision_margin"]  # (after num_depth_ties in the C struct)
 
 
 class _Outputs(ctypes.Structure):
@@ -224,6 +224,7 @@ class Oracle:
         out["num_depth_ties"] = np.zeros((H, W), np.int32)
         out["num_bounce_near_ties"] = np.zeros((H, W), np.int32)
         out["decision_margin"] = np.full((H, W), 1e30, np.float64)
+        out["hit_sequence_hash"] = np.zeros((NSTEPS, H, W), np.uint64)  # ordered composited gaussian ids per step, hashed (0: no hit)
         n = self.n
         gshape = {"dL_drgb": (n, 3), "dL_dnormal": (n, 3), "dL_df0": (n, 3), "dL_droughness": (n, 1), "dL_dopacity": (n, 1),
                   "dL_dscale": (n, 3), "dL_dmean": (n, 3), "dL_drotation": (n, 4), "total_weight": (n, 1)}

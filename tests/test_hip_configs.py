@@ -170,11 +170,11 @@ CROP_TILES += [(int(x), int(y)) for x, y in zip(np.random.default_rng(11).intege
 CROP_TILES = sorted(set(CROP_TILES))
 
 
-# measured on MI355X (profiles/r5/parity_levels.txt), asserted with a margin: (clean share of the crop, worst image dB on the clean pixels, on all traced
-# pixels, worst gradient error on all traced pixels, differing pixels)
-CROP_BARS = {("init", 2): dict(clean=0.97, psnr_clean=85.0, psnr_all=70.0, err_all=1.2e-2, differing=16),      # measured 0.980, 96.2 dB, 79.6 dB, 7.9e-3, 9
-             ("trained", 2): dict(clean=0.82, psnr_clean=70.0, psnr_all=50.0, err_all=1.5e-2, differing=330),   # measured 0.841 (13 % of the pixels hold two bounce hits within 1e-5 of each other), 83.8 dB, 57.9 dB, 9.4e-3, 283
-             ("trained", 0): dict(clean=0.985, psnr_clean=100.0, psnr_all=85.0, err_all=3e-3, differing=12)}    # measured 0.993, 117.6 dB, 96.0 dB, 1.8e-3, 5
+# measured on MI355X (profiles/r6/parity_levels.txt; the same in all three modes), asserted with a margin: (clean share of the crop, worst image dB on the clean
+# pixels, on all traced pixels, worst gradient error on all traced pixels, pixels with another hit SEQUENCE)
+CROP_BARS = {("init", 2): dict(clean=0.99, psnr_clean=85.0, psnr_all=70.0, err_all=1.2e-2, differing=60),       # measured 0.9973, 95.4 dB, 79.5 dB, 7.9e-3, 32
+             ("trained", 2): dict(clean=0.95, psnr_clean=75.0, psnr_all=50.0, err_all=1.5e-2, differing=450),   # measured 0.9624, 83.2 dB, 57.9 dB, 9.4e-3, 346
+             ("trained", 0): dict(clean=0.995, psnr_clean=105.0, psnr_all=85.0, err_all=3e-3, differing=25)}    # measured 0.9992, 117.6 dB, 96.0 dB, 1.8e-3, 10
 
 
 @pytest.mark.parametrize("mode", ["help_off", "product_default_help_on", "help_on_eight_ranks_summed"])
@@ -191,18 +191,17 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
     composites one hit more or less - the transmittance threshold, a grazing candidate, a bounce that happens or not - hangs on the
     last bits of exp() and of the bounce direction, and one such hit is up to 1e-2 of a tensor's maximum on a crop of 12k pixels. The
     fp32 oracle disagrees with ITS OWN fp64 evaluation on the hit count of 1-2 % of the pixels. So the check is PIXEL-granular:
-      * pass 1 traces the whole crop: images, gradients, per-step hit counts of both sides;
-      * a pixel is CLEAN when the HIP path composites the oracle's number of hits on every step and no two consecutive hits of the
-        oracle lie within 4 ulps of each other - on a bounce step, whose ray already carries the rounding of the steps before it, within 1e-5 -
-        (their order, hence their two weights, hangs on the last bits of t), and its forward outputs agree to 1e-3; clean pixels must be
-        >= 97 % / 82 % / 98.5 % of the crop (measured 98.0 / 84.1 / 99.3 %: with three full steps per pixel 13 % of the pixels hold two bounce hits within
-        1e-5 of each other), and a pixel with another hit count on the PRIMARY step must have a
-        REASON the oracle itself reports: its closest yes / no decision (|u|^2 vs 1, T vs the threshold, |normal| vs the bounce
-        threshold: Outputs::decision_margin) lies within 1e-3 of flipping, or it holds a 4-ulp depth tie, or the fp32 and the fp64 oracle
-        disagree on its hit counts too;
-      * pass 2 traces the clean pixels only, on both sides: every step's image >= 50 dB, all nine gradient tensors < 1e-3 of the
-        oracle's max-abs;
-      * on ALL traced pixels: >= 35 dB, gradients < 2e-2, and no more differing pixels than measured + margin.
+      * pass 1 traces the whole crop: images, gradients, per-step hit counts and the ORDERED SEQUENCE of composited gaussians of every pixel and step on
+        both sides (as a 64-bit hash: egr_debug_get_hit_sequence_hash from the HIP path's hit arena, Outputs::hit_sequence_hash from the oracle's compositing loop);
+      * a pixel is CLEAN when both sides composite the same gaussians in the same order on every step (equal hashes) and its forward outputs agree to 1e-3
+        (the total transmittance also sees the candidates behind the last composited hit - quirk Q1); clean pixels must be >= 99 / 95 / 99.5 % of the crop
+        (measured 99.7 / 96.2 / 99.9 %; rounds 4-5 compared hit COUNTS and had to exclude every pixel holding two hits within a distance window: 98.0 / 84.1 /
+        99.3 %), no more pixels may differ in sequence than between the fp32 and the fp64 oracle (+ 24), and a pixel with another sequence on the PRIMARY step
+        must have a REASON the oracle itself reports: its closest yes / no decision (|u|^2 vs 1, T vs the threshold, |normal| vs the bounce threshold:
+        Outputs::decision_margin) lies within 1e-3 of flipping, or it holds a near-tie of depths, or the fp32 and the fp64 oracle disagree on it too;
+      * pass 2 traces the clean pixels only, on both sides: every step's image >= 75 dB, ALL NINE gradient tensors (total_weight included) < 1e-3 of the
+        oracle's max-abs (measured 7.7e-5 / 6.9e-4 / 3.7e-5);
+      * on ALL traced pixels: >= 50 dB, gradients < 1.5e-2 (the fp32 oracle is 2.7e-3 ... 1.7e-2 from its own fp64 evaluation).
     The targets are moved off the scene's own wall values (normal, depth, roughness, f0): where an opaque wall renders exactly its
     target, sign(output - target) hangs on the last bit on both sides.
 
@@ -251,7 +250,7 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
                 img = hip_outputs(rt)
             rt.zero_grad()
             m.get_gaussians().total_weight.zero_()
-            rays, hits = 0, 0
+            rays, hits, seq = 0, 0, np.zeros((3, H, W), np.uint64)
             for r, w in parts:  # (grad launches ADD to the gradient tensors, like the reference's atomicAdds: eight ranks sum up)
                 m.set_partition(r, w)
                 m.get_metadata().total_num_calls.fill_(K - 1)
@@ -259,8 +258,9 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
                 assert m.get_counters()[11] == 0
                 rays += m.get_counters()[0]
                 hits = hits + m.debug_step_hits().numpy()  # (pixels outside the rank's tiles report 0)
+                seq = seq | m.debug_hit_sequence_hash().numpy().view(np.uint64)  # ordered composited gaussian ids per pixel and step, hashed (0 outside the rank's tiles)
             assert rays == int(mask.sum())
-            return img, hip_grads(rt), hits
+            return img, hip_grads(rt), hits, seq
         finally:
             m.debug_set_pixel_mask(torch.empty(0, dtype=torch.uint8))
             m.set_partition(0, 1)
@@ -288,7 +288,7 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
         return {k: float(np.abs(got[k] - ref_[k]).max() / np.abs(scale[k]).max()) for k in GRAD_KEYS}
 
     # ---- pass 1: the whole crop
-    img_h, grad_h, hits_h = hip_on(crop, images=True)
+    img_h, grad_h, hits_h, seq_h = hip_on(crop, images=True)
     ref, img_o = oracle_on(o, crop, images=True)
     ref64, _ = oracle_on(o64, crop)
     levels = image_levels(img_h, img_o, crop)
@@ -296,29 +296,39 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
     floor = errors({k: ref64[k] for k in GRAD_KEYS}, ref, ref)
     differing = np.any(hits_h != ref["num_composited_per_step"], axis=0) & crop
     differing_oracles = np.any(ref["num_composited_per_step"] != ref64["num_composited_per_step"], axis=0) & crop
-    near_tie = ((ref["num_depth_ties"] > 0) | (ref["num_bounce_near_ties"] > 0)) & crop  # (bounce steps: within 1e-5 - the ray itself carries the rounding of the steps before it)
-    # (equal hit COUNTS can still hide one hit swapped for another - a near-tie between a ray's last composited hit and the first one it does not
-    # reach -: a pixel whose forward outputs are off by more than 1e-3 anywhere is not clean either)
+    near_tie = ((ref["num_depth_ties"] > 0) | (ref["num_bounce_near_ties"] > 0)) & crop  # (a REASON for another sequence, no longer a criterion: see `clean`)
+    # CLEAN = both sides composite THE SAME GAUSSIANS IN THE SAME ORDER on every step (hashes of the ordered id sequences: egr_debug_get_hit_sequence_hash /
+    # Outputs::hit_sequence_hash) - exact, where rounds 4-5 compared hit COUNTS and excluded every pixel with two hits within a distance window
+    same_sequence = np.all(seq_h == ref["hit_sequence_hash"], axis=0)
+    same_sequence_oracles = np.all(ref["hit_sequence_hash"] == ref64["hit_sequence_hash"], axis=0)
+    assert not np.any(same_sequence & crop & np.any(hits_h != ref["num_composited_per_step"], axis=0))  # (equal hashes imply equal counts)
+    # (the total transmittance also sees the candidates BEHIND the last composited hit - quirk Q1 -: a pixel whose forward outputs are off by more than
+    # 1e-3 anywhere although its sequences agree has met one candidate more or less there; counted, and not clean either)
     off = np.zeros((H, W), bool)
     for key in ("output_rgb", "output_depth", "output_normal", "output_f0", "output_roughness", "output_transmittance", "output_total_transmittance"):
         off |= np.any(np.abs(img_h[key] - img_o[key]) > 1e-3, axis=(0, -1))
     off &= crop
-    clean = crop & ~differing & ~near_tie & ~off
+    clean = crop & same_sequence & ~off
     # every pixel with another hit count on the PRIMARY step has a reason the oracle reports itself (on a bounce step the ray itself already
     # carries the rounding of the step before it: GGX sampling amplifies the last bits of the accumulated normal)
     thin = ref["decision_margin"] < 1e-3
-    differing0 = (hits_h[0] != ref["num_composited_per_step"][0]) & crop
-    unexplained = differing0 & ~thin & ~near_tie & ~differing_oracles
+    differing0 = (seq_h[0] != ref["hit_sequence_hash"][0]) & crop
+    unexplained = differing0 & ~thin & ~near_tie & ~differing_oracles & same_sequence_oracles
     # ---- pass 2: the clean pixels only, both sides
-    img_hc, grad_hc, hits_hc = hip_on(clean, images=True)
+    img_hc, grad_hc, hits_hc, seq_hc = hip_on(clean, images=True)
     ref_c, img_oc = oracle_on(o, clean, images=True)
-    assert np.array_equal(hits_hc * clean[None], ref_c["num_composited_per_step"] * clean[None])  # (a pixel's rays do not depend on which other pixels are traced)
+    # (a pixel's rays do not depend on which other pixels are traced: pass 2 composites pass 1's sequences - bit for bit without help; with help the ORDER of
+    # exactly tied depths of a bounce ray hangs on timing, DESIGN.md 2 (a): a few pixels may swap two tied hits between the two launches, counted and bounded)
+    reordered = int(np.any((seq_hc != ref_c["hit_sequence_hash"]) & clean[None], axis=0).sum())
+    assert reordered == 0 if mode == "help_off" else reordered <= 0.005 * int(crop.sum()), reordered
     levels_clean = image_levels(img_hc, img_oc, clean)
     err_clean = errors(grad_hc, ref_c, ref)
     fmt = lambda d: {k: f"{v:.1e}" for k, v in d.items()}
     share = float(clean.sum()) / float(crop.sum())
     report(f"config_c_crop_{variant}_bounces{bounces}[{mode}]", tiles=len(CROP_TILES), pixels=int(crop.sum()), composited=ref["num_composited_per_step"].sum(axis=(1, 2)).tolist(),
-           clean_pixels=int(clean.sum()), clean_share=round(share, 4), pixels_with_other_hit_counts=int(differing.sum()), pixels_with_a_4ulp_depth_tie=int(near_tie.sum()),
+           clean_pixels=int(clean.sum()), clean_share=round(share, 4), clean_pixels_that_reordered_an_exact_tie_in_the_second_launch=reordered, pixels_with_another_hit_sequence=int((crop & ~same_sequence).sum()), of_which_on_the_primary_step=int(differing0.sum()),
+           pixels_where_fp32_and_fp64_oracle_differ_in_sequence=int((crop & ~same_sequence_oracles).sum()), same_sequence_but_outputs_off_by_1e3=int((crop & same_sequence & off).sum()),
+           pixels_with_other_hit_counts=int(differing.sum()), pixels_with_a_near_tie=int(near_tie.sum()),
            differing_with_a_decision_within_1e3=int((differing & thin).sum()), differing_where_fp32_and_fp64_oracle_differ_too=int((differing & differing_oracles).sum()),
            differing_on_the_primary_step=int(differing0.sum()), primary_step_unexplained=int(unexplained.sum()), pixels_with_outputs_off_by_1e3=int(off.sum()), pixels_where_fp32_and_fp64_oracle_differ_in_hit_counts=int(differing_oracles.sum()),
            psnr_min_all_pixels=min(levels.values()), psnr_min_clean_pixels=min(levels_clean.values()), psnr_clean_pixels=levels_clean,
@@ -326,13 +336,10 @@ def test_config_c_gradient_check_vs_oracle_at_size(ren, orc, syn, variant, bounc
     assert share >= bars["clean"], (share, int(differing.sum()), int(near_tie.sum()))
     assert int(unexplained.sum()) <= 3, np.argwhere(unexplained)[:10].tolist()  # (measured 0 / 0-1 / 1: a near-tie between the last composited hit and the first one not reached is not in the oracle's tie count)
     assert min(levels_clean.values()) >= bars["psnr_clean"] and min(levels.values()) >= bars["psnr_all"], (levels_clean, levels)
-    # (total_weight adds the raw weights of ALL steps, where the eight gradients weigh a bounce hit with the step's throughput: with three full steps per
-    # pixel it shows what the last bits of a bounce direction do to the steep edge of a gaussian's response - measured 1.0e-3, and the same with the
-    # near-tie window at 3e-5 -, so in that one case it is held to 3e-3; the eight gradient tensors are at 1e-4 and below in all three cases)
-    assert max(v_ for k_, v_ in err_clean.items() if k_ != "total_weight") < 1e-3, err_clean
-    assert err_clean["total_weight"] < (3e-3 if (variant, bounces) == ("trained", 2) else 1e-3), err_clean
+    assert max(err_clean.values()) < 1e-3, err_clean  # the north-star bar, all nine tensors (round 5 held total_weight of the three-step case to 3e-3: its "clean" pixels still hid swapped hits)
     assert max(err_all.values()) < bars["err_all"], err_all
-    assert int(differing.sum()) <= bars["differing"], (int(differing.sum()), int(differing_oracles.sum()))
+    other, other_oracles = int((crop & ~same_sequence).sum()), int((crop & ~same_sequence_oracles).sum())
+    assert other <= bars["differing"] and other <= other_oracles + 24, (other, other_oracles)  # (absolute: measured + margin; relative: no worse than fp32 against fp64 arithmetic on the oracle's side)
 
 
 # ------------------------------------------------------------------------------------------------ config scalars
