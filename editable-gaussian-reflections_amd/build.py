@@ -21,11 +21,9 @@ HIPCC = os.environ.get("HIPCC", shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: on gfx950 a v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 takes longer than the two scalar instructions it replaces (tools/ubench/valu_rate.hip:
 # 6.9 vs 2 x 3.1 cycles per SIMD), and the SLP vectoriser packs every adjacent pair of fp32 operations it finds (both chains -5 ... -7 % without it)
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wno-unused-result"]
-if os.environ.get("EGR_GPOP"):
-    HIP_FLAGS.append("-DEGR_GPOP=" + os.environ["EGR_GPOP"])
-for _k in ("EGR_FWD_WAVES", "EGR_PRIMARY_TABLE", "EGR_BWD_WAVES", "EGR_GT_SLOTS", "EGR_SAH_COLLAPSE", "EGR_PAIR_PRIMARY", "EGR_PSTK", "EGR_PIPELINE", "EGR_COMBINE_MASK", "EGR_BWD_COMPACT", "EGR_UNFUSED_CANDIDATE", "EGR_TEAM", "EGR_BOX", "EGR_DONATE_MIN", "EGR_ORDER_BUCKETS", "EGR_ORDER_SHIFT", "EGR_BWD_TEAM", "EGR_HOIST_BOUNCE", "EGR_EARLY_M", "EGR_FLUSH_WHEN_FULL", "EGR_LEAF_FILTER", "EGR_FPOP", "EGR_LEAF_ORIGIN", "EGR_KEYS_IL", "EGR_VALS_IL", "EGR_LEAN_DIV", "EGR_X1", "EGR_X2"):  # tuning experiments (tools/sweep.sh); X1 / X2 are scratch switches for one-off experiments in a working tree
-    if os.environ.get(_k):
-        HIP_FLAGS.append("-D" + _k + "=" + os.environ[_k])
+# (tuning knobs - EGR_GPOP, EGR_FPOP, EGR_PSTK, EGR_TEAM, EGR_BOX, EGR_DONATE_MIN, EGR_FWD_WAVES, EGR_BWD_WAVES, EGR_BWD_TEAM, EGR_GT_SLOTS, EGR_ORDER_BUCKETS, EGR_ORDER_SHIFT:
+# numeric constants with an #ifndef default in csrc/ - are set for a sweep through EGR_EXTRA_FLAGS="-DEGR_GPOP=4"; the alternative code paths that rounds 1-5 switched
+# between at build time are settled and gone: profiles/HISTORY.md has their measurements)
 if os.environ.get("EGR_EXTRA_FLAGS"):  # compiler-flag experiments, e.g. "-mllvm -amdgpu-sched-strategy=iterative-minreg"
     HIP_FLAGS += os.environ["EGR_EXTRA_FLAGS"].replace(",", " ").split()
 if os.environ.get("EGR_TASK_TIMES"):  # diagnostic: per-task walk / composite time of one step in the stats images (tools/task_times.py)

@@ -232,9 +232,6 @@ __global__ void __launch_bounds__(BS) k_karras(int n, const uint64_t *__restrict
 // write-through / cache-bypassing), the writer drains its stores before the counter RMW, which itself is acq_rel at agent scope.
 // Record per binary internal node: box lo[3], hi[3], T[1..7] (16 floats, 3 unused). Runs once per rebuild.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef EGR_SAH_COLLAPSE
-#define EGR_SAH_COLLAPSE 1 // 0: the round-2 heuristic (open the child with the most leaves / the largest one that dissolves completely)
-#endif
 #define EGR_DP_STRIDE 16
 __device__ __forceinline__ float ld_agent(const float *p) {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -315,8 +312,7 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
     int child[EGR_WIDTH];
     int nchild = 2;
     child[0] = left[b], child[1] = right[b];
-    auto leaves_of = [&](int id) -> uint32_t { return id >= n - 1 ? 1u : last[id] - first[id] + 1u; };
-#if EGR_SAH_COLLAPSE
+    (void)first, (void)last;
     // SAH-optimal collapse, part 2: replay the dynamic programme's decisions top-down. Every entry carries the number of slots the
     // optimum grants its subtree; an internal entry with more than one slot is replaced by its two children with the split that
     // attains D(node, slots) (kept in Morton order) - unless the extra slots do not pay (T(node, i) == T(node, i - 1)).
@@ -348,27 +344,6 @@ __global__ void __launch_bounds__(BS) k_collapse_level(int n, uint32_t count, co
             child[at + 1] = right[id], budget[at + 1] = b - k;
             nchild++; // (sum of budgets <= 8 and every entry holds >= 1: never more than 8 entries)
         }
-    }
-#endif
-    while (!EGR_SAH_COLLAPSE && nchild < EGR_WIDTH) {
-        // Which internal child to open: the largest one whose WHOLE subtree still fits into the free slots (it dissolves into
-        // this node instead of becoming an under-filled node of its own: fewer, fuller nodes = fewer 128-B node visits per
-        // ray); if none fits, the largest one (keeps the upper levels balanced).
-        const uint32_t free_slots = (uint32_t)(EGR_WIDTH - nchild);
-        int best = -1, fit = -1;
-        uint32_t best_leaves = 1, fit_leaves = 1;
-        for (int k = 0; k < nchild; k++) {
-            uint32_t l = leaves_of(child[k]);
-            if (l > best_leaves) best_leaves = l, best = k;
-            if (l > fit_leaves && l - 1u <= free_slots) fit_leaves = l, fit = k;
-        }
-        if (fit >= 0) best = fit;
-        if (best < 0) break; // only leaves left
-        const int id = child[best];
-        child[best] = left[id]; // keep the Morton order of the children: insert the right child just after
-        for (int k = nchild; k > best + 1; k--) child[k] = child[k - 1];
-        child[best + 1] = right[id];
-        nchild++;
     }
     for (int k = 0; k < EGR_WIDTH; k++) {
         uint32_t link = EGR_EMPTY_SLOT;
@@ -545,10 +520,8 @@ void egr_bvh_rebuild(egr_context *c, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(k_karras, dim3(nblk(n - 1)), dim3(BS), 0, s, (int)n, c->keys_out, c->k_left, c->k_right, c->k_parent, c->k_first,
                            c->k_last);
-#if EGR_SAH_COLLAPSE
         EGR_HIP(hipMemsetAsync(c->k_flags, 0, (size_t)n * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_sah_bottom_up, dim3(nblk(n)), dim3(BS), 0, s, (int)n, c->k_left, c->k_right, c->k_parent, c->aabb, c->vals_out, c->k_flags, c->k_dp);
-#endif
         // level-by-level collapse; frontiers ping-pong in keys_in (free after the sort)
         uint32_t *fr0 = reinterpret_cast<uint32_t *>(c->keys_in), *fr1 = fr0 + c->n_alloc;
         uint32_t init[4] = {1u, 0u, 0u, 0u}; // wide node 0 = binary root

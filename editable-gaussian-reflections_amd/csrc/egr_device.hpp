@@ -52,16 +52,13 @@ EGR_DI float eval_gaussian_sq(float sq, float exp_power) { return expf(-pow_exp(
 EGR_DI uint32_t f2u(float f) { return __float_as_uint(f); }
 EGR_DI float u2f(uint32_t u) { return __uint_as_float(u); }
 
-#ifndef EGR_LEAN_DIV
-#define EGR_LEAN_DIV 1
-#endif
 #pragma clang fp contract(off)
 // IEEE square root and division of the hot per-candidate / per-hit / per-ray arithmetic WITHOUT the range scaling the compiler's expansions carry (v_div_scale / v_div_fixup,
 // the 2^32 pre-scaling of a denormal radicand): the same correction steps on the same hardware approximations - the sequence the compiler emits
 // for `sqrtf(x)` and `a / b` with the scaling taken out, so the results are the correctly rounded ones whenever no intermediate leaves the normal
 // range (|W d| of a usable gaussian is within 1e-15 ... 1e15). 17 of the 75 instructions of a rejected candidate; quotients that share a
-// denominator share its refined reciprocal. EGR_LEAN_DIV=0 (build.py) puts the compiler's expansions back (use it with EGR_UNFUSED_CANDIDATE=1).
-#if defined(__HIP_DEVICE_COMPILE__) && EGR_LEAN_DIV
+// denominator share its refined reciprocal.
+#if defined(__HIP_DEVICE_COMPILE__)
 EGR_DI float egr_sqrt_rn(float x) {
     const float s = __builtin_amdgcn_sqrtf(x); // within 1 ulp
     const float sd = u2f(f2u(s) - 1u), su = u2f(f2u(s) + 1u);
@@ -77,7 +74,7 @@ EGR_DI float egr_div_rn(float a, float b, float r) { // a / b, r = egr_rcp_refin
     const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), r, q0);
     return __builtin_fmaf(__builtin_fmaf(-b, q1, a), r, q1);
 }
-#else
+#else // (host pass of the translation unit)
 EGR_DI float egr_sqrt_rn(float x) { return sqrtf(x); }
 EGR_DI float egr_rcp_refined(float) { return 0.0f; }
 EGR_DI float egr_div_rn(float a, float b, float) { return a / b; }

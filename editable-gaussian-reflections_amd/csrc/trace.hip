@@ -40,28 +40,10 @@
 #ifndef EGR_GPOP
 #define EGR_GPOP 5 // pair walk: a walk batch pops up to 8 x EGR_GPOP (ray, node) pairs, EGR_GPOP per lane group (5 since the loop is instantiated per decode: 62 -> 41 spilled VGPRs; before that 4 was best)
 #endif
-#ifndef EGR_PIPELINE
-#define EGR_PIPELINE 1 // pair walk: issue an evaluation batch's record fetches and a walk batch's node fetches together (0: one kind of batch per iteration)
-#endif
 #define EGR_WALK_MAX_LEAVES (8 * EGR_GPOP * EGR_WIDTH) // leaf pairs one walk batch can add
-#define EGR_LBUF (64 + (EGR_PIPELINE ? 2 : 1) * EGR_WALK_MAX_LEAVES)
-#ifndef EGR_PAIR_PRIMARY
-#define EGR_PAIR_PRIMARY 0 // 1: primary rays walk pairwise too (0: one packet per tile)
-#endif
+#define EGR_LBUF (64 + 2 * EGR_WALK_MAX_LEAVES) // (an evaluation batch and a walk batch are issued together: room for two walk batches' leaves)
 #ifndef EGR_FPOP
-#define EGR_FPOP 2 // frustum walk: 8 x EGR_FPOP nodes per iteration (two interleaved same-box pairs: forward chain 3.80-3.87 against 3.92-3.95 ms dense-init; 3 and 4 no further - and with EGR_LEAF_ORIGIN the ray table holds the origins of at most 64 + 8 x 2 x 8 buffered leaves: a static_assert says so)
-#endif
-#ifndef EGR_LEAF_FILTER
-#define EGR_LEAF_FILTER 1 // primary tiles: the leaves the frustum walk found are tested once more, one lane per leaf - bounding sphere against the tile's pyramid - before every lane evaluates them
-#endif
-#ifndef EGR_VALS_IL
-#define EGR_VALS_IL 1 // (alpha, record) pairs in lane-interleaved groups of two
-#endif
-#ifndef EGR_KEYS_IL
-#define EGR_KEYS_IL 1 // candidate keys in lane-interleaved groups of four (a scan's 16-B loads are consecutive for the wave)
-#endif
-#ifndef EGR_LEAF_ORIGIN
-#define EGR_LEAF_ORIGIN 1 // primary tiles: a leaf's object-space origin W o + w computed once per leaf (one lane) and broadcast through LDS instead of per ray
+#define EGR_FPOP 2 // frustum walk: 8 x EGR_FPOP nodes per iteration (two interleaved same-box pairs: forward chain 3.80-3.87 against 3.92-3.95 ms dense-init; 3 and 4 no further - and the ray table holds the origins of at most 64 + 8 x 2 x 8 buffered leaves: a static_assert says so)
 #endif
 #ifndef EGR_PSTK
 #define EGR_PSTK 512 // pair-stack entries kept in LDS
@@ -124,29 +106,17 @@ EGR_DI f3 primary_direction(const DeviceView &v, int ix, int iy, bool jitter, ui
 
 // The geometry of one (ray, gaussian) pair - object-space ray, closest-approach point, the two rejections that only need those
 // (shaders.cu:19-20, 36, 41-51) - in ONE function shared by the forward's candidate test and the backward's recomputation (bit-identical
-// t and u on both sides). EGR_UNFUSED_CANDIDATE = 1 compiles it without fma contraction, operation for operation what the CPU oracle
-// (-ffp-contract=off) and an unfused reading of the source evaluate; 0 lets the compiler fuse (nvcc's default for the reference too).
-#ifndef EGR_UNFUSED_CANDIDATE
-#define EGR_UNFUSED_CANDIDATE 0
-#endif
+// t and u on both sides), with fused multiply-adds (nvcc's default for the reference too; the CPU oracle evaluates unfused, -ffp-contract=off).
 // Which products of `a b + c d + e f` are fused is the compiler's choice PER CALL SITE (it differs between a uniform and a per-lane origin, and between
 // two instantiations of one template), while the forward's primary tiles, its pair walk - owner's and helpers' copies - and the backward's
 // recomputation must agree to the bit: the fusion is spelled out (the pattern the compiler applied to these expressions in rounds 1-5:
 // fma(e, f, fma(a, b, c d))) and the functions themselves are compiled without contraction.
 #pragma clang fp contract(off)
 EGR_DI float egr_dot3(float ax, float ay, float az, float bx, float by, float bz) {
-#if EGR_UNFUSED_CANDIDATE
-    return ax * bx + ay * by + az * bz;
-#else
     return __builtin_fmaf(az, bz, __builtin_fmaf(ax, bx, ay * by));
-#endif
 }
 EGR_DI float egr_madd(float a, float b, float c) { // a b + c
-#if EGR_UNFUSED_CANDIDATE
-    return a * b + c;
-#else
     return __builtin_fmaf(a, b, c);
-#endif
 }
 EGR_DI f3 egr_div3_rn(const f3 &a, const f3 &b, const f3 &r) { return mk3(egr_div_rn(a.x, b.x, r.x), egr_div_rn(a.y, b.y, r.y), egr_div_rn(a.z, b.z, r.z)); } // a / b per component, r = refined reciprocals of b
 EGR_DI float egr_gaussian_sq(float sq, float exp_power) { // eval_gaussian_sq (kernel.cu:8-12) with the division by the launch constant 2p spelled out: its reciprocal is loop-invariant
@@ -420,13 +390,8 @@ EGR_DI void pair_eval_append(const DeviceView &v, const FwdConst &fc, WalkShared
     const bool in_ext = res == 2 && at >= v.cand_cap;
     if (res == 2 && !in_ext) {
         const size_t slot = (scratch0 + er) * v.cand_cap + at;
-#if EGR_KEYS_IL
         v.cand_keys[scratch0 * v.cand_cap + ((((size_t)(at >> 2) * EGR_WAVE + er) << 2) + (at & 3u))] = t; // (forward_decl.inc: EGR_KEY_AT of the owner's region)
         v.cand_vals[slot] = make_float2(alpha, u2f(pidx)); // (a pair walk's lists are contiguous runs: forward_decl.inc)
-#else
-        v.cand_keys[slot] = t;
-        v.cand_vals[slot] = make_float2(alpha, u2f(pidx)); // (a pair walk's lists are contiguous runs: forward_decl.inc)
-#endif
     }
     if (__ballot(in_ext) != 0ull) { // rare: some list outgrew its run - it continues in ONE extension block per ray
         for (;;) { // rays that need a block and have none, one after the other (wave-uniform loop)
@@ -515,7 +480,7 @@ EGR_DI void pair_walk(const DeviceView &v, const FwdConst &fc, WalkShared &mine,
         }
         // ---------------- issue: walk batch (pop up to 8 x EGR_GPOP (ray, node) pairs)
         // (a walk batch only runs when the leaf pairs it can add fit the buffer: otherwise this iteration only evaluates)
-        const uint32_t npop = ((EGR_PIPELINE || !do_eval) && nl + (uint32_t)EGR_WALK_MAX_LEAVES <= (uint32_t)EGR_LBUF) ? min(top, 8u * (uint32_t)EGR_GPOP) : 0u;
+        const uint32_t npop = nl + (uint32_t)EGR_WALK_MAX_LEAVES <= (uint32_t)EGR_LBUF ? min(top, 8u * (uint32_t)EGR_GPOP) : 0u;
         uint32_t pw[EGR_GPOP];
         uint4 sl_[EGR_GPOP];
         if constexpr (TEAM > 1) hungry_seen = lds_peek(&team.hungry); // (read with the stack: one LDS round trip)
@@ -802,14 +767,8 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
 // record index) and flushed once per tile: ~8x fewer global atomics than backward_pass.cu:210-220's 15/22 per hit.
 #ifndef EGR_GT_SLOTS
 #define EGR_GT_SLOTS 80 // slots of the primary step's LDS table (any count >= 64; multiply-shift hash). Since a full table is flushed and refilled
-                        // (EGR_FLUSH_WHEN_FULL, round 4) a smaller one is as good: 64 / 72 / 80 / 94 slots -> 3.02 / 3.05 / 3.01-3.03 / 3.11 ms backward chain
+                        // (round 4) a smaller one is as good: 64 / 72 / 80 / 94 slots -> 3.02 / 3.05 / 3.01-3.03 / 3.11 ms backward chain
                         // dense-init (same box). Before that: 94 beat 64 (hits without a slot left as records of their own), 128 and 256 cost waves per CU
-#endif
-#ifndef EGR_FLUSH_WHEN_FULL
-#define EGR_FLUSH_WHEN_FULL 1 // primary backward: a hit that finds no table slot makes the wave flush the table and look again (0: such hits leave as records of their own)
-#endif
-#ifndef EGR_PRIMARY_TABLE
-#define EGR_PRIMARY_TABLE 1 // 0 (measured: 4.8 instead of 3.3 ms): primary hits skip the LDS table and leave as records like bounce hits
 #endif
 #define EGR_GT_COMPS 22
 #define EGR_GT_STRIDE 23 // floats per table slot ([slot][component], odd stride: lanes on different slots fall on different LDS banks)
@@ -879,12 +838,6 @@ EGR_DI uint32_t grad_table_flush(const DeviceView &v, uint32_t *gt_keys, float *
     return sent;
 }
 
-#ifndef EGR_EARLY_M
-#define EGR_EARLY_M 1 // backward, per-hit geometry: the M rows requested together with the W rows
-#endif
-#ifndef EGR_COMBINE_MASK
-#define EGR_COMBINE_MASK 0 // (round 4, with the flushed table: no level beyond lane ^ 1, lane ^ 8 - 2.95-2.97 against 3.01-3.03 ms with lane ^ 2; it was 1) primary backward: register-level pre-sums of equal neighbours beyond lane ^ 1 and lane ^ 8: bit 0: lane ^ 2, 1: lane ^ 4, 2: lane ^ 16, 3: lane ^ 32
-#endif
 // The 22 gradient components of the PRIMARY hits of one hit row (one per lane; `pos` = record index) on their way into the wave's LDS table, in two
 // calls: primary_presum (1), then primary_table_add (2, 3), which returns true for a lane whose contribution found no slot and has to leave
 // as two records of its own.
@@ -923,18 +876,6 @@ EGR_DI bool primary_presum(const uint32_t pos, float (&gx)[EGR_GT_COMPS], const 
     }
         EGR_COMBINE(1u, EGR_FETCH_DPP, 0xB1)  // quad_perm [1,0,3,2]: lane ^ 1
         EGR_COMBINE(8u, EGR_FETCH_DPP, 0x128) // row_ror 8: lane ^ 8
-#if EGR_COMBINE_MASK & 1
-        EGR_COMBINE(2u, EGR_FETCH_DPP, 0x4E)  // quad_perm [2,3,0,1]: lane ^ 2 (survivors of the first level, two pixels apart)
-#endif
-#if EGR_COMBINE_MASK & 2
-        EGR_COMBINE(4u, EGR_FETCH_DPP4, 0)    // lane ^ 4 = (lane ^ 7) ^ 3: row_half_mirror, then quad_perm [3,2,1,0]
-#endif
-#if EGR_COMBINE_MASK & 4
-        EGR_COMBINE(16u, EGR_FETCH_SWZ, 0x401F) // lane ^ 16: two rows of pixels apart
-#endif
-#if EGR_COMBINE_MASK & 8
-        EGR_COMBINE(32u, EGR_FETCH_X32, 0)      // lane ^ 32
-#endif
 #undef EGR_COMBINE
 #undef EGR_FETCH_DPP
 #undef EGR_FETCH_SWZ
@@ -952,7 +893,7 @@ EGR_DI bool primary_table_add(const DeviceView &v, const bool want, const uint32
         slot = ((((pos * 2654435761u) >> 16) * (uint32_t)EGR_GT_SLOTS) >> 16); // keyed by record index (multiply-shift: any slot count)
         found = false;
 #pragma unroll 1
-        for (int pr = 0; pr < ((want && EGR_PRIMARY_TABLE) ? 8 : 0); pr++) {
+        for (int pr = 0; pr < (want ? 8 : 0); pr++) {
             uint32_t key = *reinterpret_cast<volatile uint32_t *>(&gt_keys[slot]);
             if (key == EGR_GT_EMPTY) key = atomicCAS(&gt_keys[slot], EGR_GT_EMPTY, pos), key = key == EGR_GT_EMPTY ? pos : key; // (another lane of this row may have taken it meanwhile)
             if (key == pos) { found = true; break; }
@@ -960,12 +901,10 @@ EGR_DI bool primary_table_add(const DeviceView &v, const bool want, const uint32
         }
     };
     probe();
-#if EGR_FLUSH_WHEN_FULL
     if (__ballot(want && !found) != 0ull) {
         records += grad_table_flush(v, gt_keys, gt_vals, stage, lane);
         probe();
     }
-#endif
     bool pending = found; // this lane's contribution still has to be added to its table slot
     while (__ballot(pending) != 0ull) { // the rounds of the table update (wave-uniform loop)
         if (pending) gt_claim[slot] = (uint32_t)lane;
@@ -992,9 +931,7 @@ template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float
     const float opacity = a2.z, scaling_factor = a2.w;
     // recompute the local hit exactly as the forward did
     const float4 W0 = v.inst_w[4 * pos], W1 = v.inst_w[4 * pos + 1], W2 = v.inst_w[4 * pos + 2];
-#if EGR_EARLY_M
     const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3]; // (requested with W: left where they are used, the compiler issues them ~ 500 instructions later and the row waits a second time)
-#endif
     f3 lo, ld, dhat, u;
     float t_unused;
     bool behind_unused, outside_unused;
@@ -1012,9 +949,6 @@ template <class GX> EGR_DI void hit_geometry_fn(const DeviceView &v, const float
                                dot(mk3(W0.z, W1.z, W2.z), dL_dx_local)) * scaling_factor; // :161-167
     const f3 dl2w0 = -dL_dx_world.x * local_hit, dl2w1 = -dL_dx_world.y * local_hit, dl2w2 = -dL_dx_world.z * local_hit;
     const f3 d_mean = -dL_dx_world;
-#if !EGR_EARLY_M
-    const float4 M0 = v.inst_m[4 * pos], M1 = v.inst_m[4 * pos + 1], M2 = v.inst_m[4 * pos + 2], qu = v.inst_m[4 * pos + 3];
-#endif
     const f3 scaling = mk3(M0.w, M1.w, M2.w); // exp(scale), stored by k_instances
     const f3 den = mk3(scaling.x * scaling_factor + eps_scale_grad, scaling.y * scaling_factor + eps_scale_grad,
                        scaling.z * scaling_factor + eps_scale_grad);
@@ -1083,14 +1017,8 @@ template <int TEAM> struct BwdTeamShared {
 // The backward half of the fused per-tile chain (see k_forward_chain): a wave takes a tile's backward through all its steps - the
 // primary step (22 gradient components per hit through the LDS table), then the bounce steps, last bounce first (15 components per
 // hit, straight out as wide adds; in the team build their batches can be taken by team mates). Per-step code: backward_task.inc.
-#ifndef EGR_BWD_COMPACT
-#define EGR_BWD_COMPACT 1 // bounce-step backward: per-ray suffix sums first, then the per-hit geometry with one lane per HIT (backward_task.inc)
-#endif
 #ifndef EGR_BWD_WAVES
 #define EGR_BWD_WAVES 3
-#endif
-#ifndef EGR_HOIST_BOUNCE
-#define EGR_HOIST_BOUNCE 1 // bounce-step backward, pass 1: a chunk's eight fetches issued before its arithmetic (0: each row fetches for itself; backward chain 2.72 -> 2.66 ms trained-like, 2.645 -> 2.61 dense-init)
 #endif
 // Between the two chains of a grad launch: the order in which the backward chain takes this strand's tasks. The forward chain knows what a
 // tile's backward will cost (its hit rows and hits), and a persistent-wave kernel ends with a tail as long as the tiles that START LATE and
@@ -1179,7 +1107,6 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
     if (threadIdx.x == 0) bteam.done = 0u;
     if (threadIdx.x < TEAM) bteam.ticket[threadIdx.x] = 0u, bteam.nitems[threadIdx.x] = 0u, bteam.finished[threadIdx.x] = 0u;
     uint32_t bepoch = 0u;
-#if EGR_BWD_COMPACT
     // the two queues of the bounce steps live in the table's memory: the table is empty (flushed, all zero) while a tile's bounce steps run -
     // they come before its primary step - and the words they dirtied are cleared again before that step (backward_task.inc).
 #define EGR_BQ_FLOATS (25 * EGR_WAVE) // floats of the table's memory the bounce steps use
@@ -1187,7 +1114,6 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
     uint4 *bitems = reinterpret_cast<uint4 *>(gt_vals);  // [4 x 64] bounce steps: (ray, dL/dalpha, record, weight) of the hits of a chunk of four rows
     float *bdl = gt_vals + 16 * EGR_WAVE;                // [3 x 64] bounce steps: the rays' radiance gradient
     float *bray = gt_vals + 19 * EGR_WAVE;               // [6 x 64] bounce steps: the rays (origin, direction)
-#endif
     for (int s = lane; s < EGR_GT_SLOTS; s += EGR_WAVE) gt_keys[s] = EGR_GT_EMPTY;
     for (int s = lane; s < EGR_GT_STRIDE * EGR_GT_SLOTS; s += EGR_WAVE) gt_vals[s] = 0.0f;
     __syncthreads(); // the kernel's only workgroup barrier (a team's waves run independently from here on)
@@ -1225,13 +1151,11 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
 #include "backward_task.inc"
             } while (false);
         }
-#if EGR_BWD_COMPACT
         if (table_dirty) { // (the table's memory held the bounce steps' queues: empty again for the next tile's primary step)
             EGR_BWD_SYNC();
             for (int s = lane; s < EGR_BQ_FLOATS; s += EGR_WAVE) gt_vals[s] = 0.0f;
             EGR_BWD_SYNC();
         }
-#endif
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8
         {
             const unsigned long long bw_t2 = __builtin_amdgcn_s_memrealtime();
