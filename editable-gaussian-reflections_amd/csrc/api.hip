@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "egr_internal.hpp"
+#include "egr_device.hpp" // egr_div_rn / egr_sqrt_rn: the debug kernel below runs exactly the functions the hot kernels use
 
 void egr_copy_final_to_denoised(egr_context *c, hipStream_t s);
 void egr_denoise_atrous(egr_context *c, hipStream_t s); // denoise.hip
@@ -355,6 +356,20 @@ int egr_debug_get_step_hits(egr_context *c, int32_t *host_out, void *stream) {
 int egr_debug_get_hit_sequence_hash(egr_context *c, uint64_t *host_out, void *stream) {
     if (!c || !host_out || require_ready(c, false)) return 1;
     return guarded(c, [&] { egr_export_hit_hash(c, host_out, (hipStream_t)stream); });
+}
+
+// Unit test hook for the division / square root of the hot arithmetic (egr_device.hpp): quot[i] = egr_div_rn(a[i], b[i], egr_rcp_refined(b[i])), root[i] = egr_sqrt_rn(a[i]).
+__global__ void k_debug_lean_arith(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ quot, float *__restrict__ root, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    quot[i] = egr_div_rn(a[i], b[i], egr_rcp_refined(b[i]));
+    root[i] = egr_sqrt_rn(a[i]);
+}
+int egr_debug_lean_arith(int device, const float *a, const float *b, float *quot, float *root, uint32_t n, void *stream) {
+    if (!a || !b || !quot || !root) return 1;
+    if (hipSetDevice(device) != hipSuccess) return 1;
+    if (n) hipLaunchKernelGGL(k_debug_lean_arith, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a, b, quot, root, n);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int egr_debug_check_bvh(egr_context *c, void *stream) {

@@ -420,8 +420,10 @@ struct Raytracer : torch::CustomClassHolder {
     }
     // pose + scalars of a view in one launch (egr_set_camera_from_dataset): R = the dataset's c2w rotation [3,3], centre = camera_center [3], fp32 CUDA tensors
     void set_camera(Tensor R, Tensor centre, double fov, double znear, double zfar) {
-        TORCH_CHECK(R.is_cuda() && centre.is_cuda() && R.numel() == 9 && centre.numel() == 3, "set_camera: CUDA tensors [3,3] and [3] expected");
-        Tensor r = R.to(torch::kFloat32).contiguous(), cc = centre.to(torch::kFloat32).contiguous();
+        // (the reference's copy_ calls - gaussian_raytracer.py:98-100 - take tensors of any device: a CPU tensor is moved to this tracer's device first)
+        TORCH_CHECK(R.dim() == 2 && R.size(0) == 3 && R.size(1) == 3 && centre.numel() == 3, "set_camera: tensors [3,3] and [3] expected");
+        const auto dev = framebuffer_data->output_rgb.device();
+        Tensor r = R.to(dev, torch::kFloat32).contiguous(), cc = centre.to(dev, torch::kFloat32).contiguous();
         check(egr_set_camera_from_dataset(ctx, r.data_ptr<float>(), cc.data_ptr<float>(), (float)fov, (float)znear, (float)zfar, current_stream()), "set_camera");
     }
     // the six target images of a training view, channel-major ([C,H,W] contiguous fp32 CUDA tensors; an undefined / empty tensor = absent = zeros), written into
@@ -435,8 +437,10 @@ struct Raytracer : torch::CustomClassHolder {
         for (int b = 0; b < 6; b++) {
             p[b] = nullptr;
             if (!in[b]->has_value() || (*in[b])->numel() == 0) continue;
-            TORCH_CHECK((*in[b])->is_cuda() && (*in[b])->numel() == ch[b] * width * height, "set_targets_chw: [C,H,W] CUDA tensor expected");
-            keep[b] = (*in[b])->to(torch::kFloat32).contiguous();
+            // (the reference's `buf.copy_(val.moveaxis(0, -1))` raises on any other shape and accepts any device: same here - a [H,W,C] tensor must not be read as [C,H,W])
+            const Tensor &t = **in[b];
+            TORCH_CHECK(t.dim() == 3 && t.size(0) == ch[b] && t.size(1) == height && t.size(2) == width, "set_targets_chw: target ", b, " must be a [", ch[b], ",", height, ",", width, "] tensor (channel-major), got ", t.sizes());
+            keep[b] = t.to(framebuffer_data->output_rgb.device(), torch::kFloat32).contiguous();
             p[b] = keep[b].data_ptr<float>();
         }
         check(egr_set_targets_chw(ctx, p[0], p[1], p[2], p[3], p[4], p[5], current_stream()), "set_targets_chw");
@@ -609,11 +613,21 @@ static void fused_adam_step(std::vector<torch::Tensor> params, std::vector<torch
     TORCH_CHECK(rc == 0, egr_fused_step_last_error());
 }
 
+// unit-test hook (egr_debug_lean_arith): (a / b, sqrt(a)) as the hot kernels' division and square root compute them
+static std::tuple<torch::Tensor, torch::Tensor> debug_lean_arith(const torch::Tensor &a, const torch::Tensor &b) {
+    TORCH_CHECK(a.is_cuda() && b.is_cuda() && a.numel() == b.numel(), "debug_lean_arith: two GPU tensors of one size expected");
+    auto x = a.to(torch::kFloat32).contiguous(), y = b.to(torch::kFloat32).contiguous();
+    auto q = torch::zeros_like(x), r = torch::zeros_like(x);
+    TORCH_CHECK(egr_debug_lean_arith(x.get_device(), x.data_ptr<float>(), y.data_ptr<float>(), q.data_ptr<float>(), r.data_ptr<float>(), (uint32_t)x.numel(), current_stream()) == 0, "debug_lean_arith failed");
+    return {q, r};
+}
+
 TORCH_LIBRARY(simple_knn, m) { m.def("distCUDA2(Tensor points) -> Tensor", &dist_hip2); }
 TORCH_LIBRARY(egr, m) {
     m.def("fused_adam_step(Tensor[] params, Tensor[] grads, Tensor[] rt_params, Tensor[] rt_grads, Tensor[] exp_avg, Tensor[] exp_avg_sq, float[] lrs, "
           "float[] clamp_min, float[] clamp_max, float[] log_decay, int step, float beta1, float beta2, float eps, int[] group_steps=[]) -> ()",
           &fused_adam_step);
+    m.def("debug_lean_arith(Tensor a, Tensor b) -> (Tensor, Tensor)", &debug_lean_arith);
 }
 
 TORCH_LIBRARY(raytracer, m) {

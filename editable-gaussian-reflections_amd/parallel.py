@@ -75,15 +75,21 @@ def all_reduce_flat(flat, group=None):
     return flat
 
 
-def all_reduce_launch_delta(grad_flat, grad_delta, group=None):
-    """The exchange step of one training iteration: `grad_delta` holds what THIS launch produced on this rank (the launch STORES
-    its sums there instead of adding to `grad_flat`: csrc/torch_binding.cpp GaussianDataHolder::grad_delta, egr_set_grad_overwrite -
-    the buffer needs no clearing between launches). Sum it over the ranks with one collective and fold it into the persistent
-    buffer: two passes over [22N] per iteration besides the collective (round 3: four - add, clear, and the read half of the
-    launch's "+="). Reducing `grad_flat` itself would multiply everything it already holds - total_weight since the last prune,
-    gradients of an earlier launch that were not zeroed - by the world size each time."""
+def all_reduce_launch_delta(grad_flat, grad_delta, group=None, cuda_module=None):
+    """The exchange step of one training iteration. `grad_delta` holds what the grad launches SINCE THE LAST FOLD produced on this rank: the
+    first launch after `grad_delta_consumed()` STORES its sums there (rows without a contribution store zeros: nobody clears the buffer),
+    every further launch before the next fold ADDS (csrc/torch_binding.cpp GaussianDataHolder::grad_delta, egr_set_grad_overwrite,
+    egr_grad_delta_consumed). This sums the buffer over the ranks with one collective and folds it into the persistent `grad_flat`:
+    two passes over [22N] per iteration besides the collective. Reducing `grad_flat` itself would multiply everything it already
+    holds - total_weight since the last prune, gradients of an earlier launch that were not zeroed - by the world size each time.
+
+    THE LIBRARY MUST THEN BE TOLD that the buffer is consumed, or the next launch adds to the already rank-summed values and the
+    next reduce sums them again: pass `cuda_module` (the Raytracer) and this function does it; a caller that passes none calls
+    `cuda_module.grad_delta_consumed()` itself right after (GaussianRaytracer.all_reduce_grads does)."""
     all_reduce_flat(grad_delta, group)
     grad_flat.add_(grad_delta)
+    if cuda_module is not None:
+        cuda_module.grad_delta_consumed()
     return grad_flat
 
 

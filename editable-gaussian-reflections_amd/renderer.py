@@ -163,8 +163,7 @@ class GaussianRaytracer:
         No-op when the tracer is not partitioned."""
         g = self.cuda_module.get_gaussians()
         if g.grad_delta.numel():
-            all_reduce_launch_delta(g.grad_flat, g.grad_delta, self.group)
-            self.cuda_module.grad_delta_consumed()
+            all_reduce_launch_delta(g.grad_flat, g.grad_delta, self.group, cuda_module=self.cuda_module)  # (reduce + fold + "consumed" in one call: they must not be separated)
 
     def _partitioned_eval(self, eval_mode=None):
         """Evaluation (no-grad) renders of a partitioned tracer in "gather" mode: with a process group of the partition's size every rank

@@ -165,7 +165,8 @@ int egr_set_camera_from_dataset(egr_context *ctx, const float *rotation_c2w_data
 /* Target upload (replaces the caller's six `framebuffer.target_*.copy_(image.moveaxis(0, -1))` of renderer/gaussian_raytracer.py:109-137, which
  * stay valid): device pointers to channel-major fp32 images ([3][H][W] diffuse, specular, normal, f0; [1][H][W] depth, roughness), NULL = the
  * target is absent and reads zero (the reference zeroes the buffer). ONE launch writes the framebuffer's pixel-major target buffers for the pixels
- * of THIS context's partition only - the only target pixels its launches read. Asynchronous on the stream. */
+ * of THIS context's partition only - the only target pixels its launches read; the target_* buffers OUTSIDE the partition's tiles keep whatever they held
+ * (undefined for a caller that reads them; a context that is switched to another partition or to the whole image uploads its targets again). Asynchronous on the stream. */
 int egr_set_targets_chw(egr_context *ctx, const float *diffuse, const float *specular, const float *depth, const float *normal, const float *roughness,
                         const float *f0, void *hip_stream);
 
@@ -266,6 +267,13 @@ int egr_debug_get_hit_sequence_hash(egr_context *ctx, uint64_t *host_out, void *
  * no statistics, no gradient contribution. The CPU oracle has the same hook (orc_set_pixel_mask), so both sides can trace exactly the pixels
  * whose per-step hit counts agree (tests/test_hip_configs.py: the at-size gradient check). Takes effect at the next egr_raytrace. */
 int egr_debug_set_pixel_mask(egr_context *ctx, const uint8_t *device_mask);
+/* Unit-test hook: the division and square root of the hot per-candidate / per-hit arithmetic (csrc/egr_device.hpp: the compiler's IEEE correction steps without
+ * its range scaling). quot[i] = a[i] / b[i], root[i] = sqrt(a[i]) as THOSE functions compute them; device pointers, n elements each. ACCEPTED DOMAIN: the results
+ * are the correctly rounded ones whenever 2^-100 <= |b| <= 2^100, |a / b| is a normal number or 0, and a is 0 or a normal number >= 2^-100 for the root
+ * (tests/test_hip_parity.py holds them to `/` and sqrtf bit for bit over that domain); outside it - b = 0, b = inf, a = inf, denormal radicands - they return NaN
+ * or a result that is off in the last bits where IEEE gives inf / 0 / a denormal: a degenerate gaussian (all-zero quaternion, |W d| out of range) then drops out of
+ * a ray's list through the NaN comparisons instead of contributing an inf. Asynchronous on the stream. */
+int egr_debug_lean_arith(int device, const float *a, const float *b, float *quot, float *root, uint32_t n, void *hip_stream);
 /* BVH self-check: every leaf box equals its instance box, every internal box is the union of its children,
  * every visible instance is reachable exactly once. Returns 0 if consistent. Host-side; synchronises. */
 int egr_debug_check_bvh(egr_context *ctx, void *hip_stream);

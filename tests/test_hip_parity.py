@@ -841,3 +841,37 @@ def test_axis_parallel_rays_are_pruned_like_their_neighbours(ren, orc, syn):
     row, nbr = tr[H // 2, :].mean(), 0.5 * (tr[H // 2 - 1, :].mean() + tr[H // 2 + 1, :].mean())
     report("axis_parallel_rays", centre_column_over_neighbours=round(col / nb, 2), centre_row_over_neighbours=round(row / nbr, 2))
     assert col < 1.5 * nb and row < 1.5 * nbr, (col, nb, row, nbr)
+
+
+def test_lean_division_and_square_root_are_ieee_on_their_domain(ren):
+    """egr_div_rn / egr_sqrt_rn (csrc/egr_device.hpp) replace every `/` and sqrtf of the candidate test, the step epilogue and the backward with the
+    compiler's own correction steps WITHOUT its range scaling (v_div_scale / v_div_fixup, the 2^32 pre-scaling of the radicand). On the accepted domain
+    (include/egr_raytracer.h: egr_debug_lean_arith) the results are IEEE's, bit for bit - held against numpy's float32 division / square root over 4M random
+    operand pairs spanning 2^-60 ... 2^60 and a list of hand-picked ones; outside the domain the deviation is documented, and shown here."""
+    importlib.import_module(PKG).load_library()
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    mant = lambda: rng.uniform(1.0, 2.0, n).astype(np.float32)
+    a = (mant() * np.exp2(rng.integers(-60, 60, n)).astype(np.float32) * rng.choice(np.float32([-1, 1]), n)).astype(np.float32)
+    b = (mant() * np.exp2(rng.integers(-60, 60, n)).astype(np.float32) * rng.choice(np.float32([-1, 1]), n)).astype(np.float32)
+    hand_a = np.float32([1, 1, 2, 3, 0, -0.0, 1e-30, 1e30, 0.1, 7, 16777216, 16777217, 1.0000001, 0.99999994, 5e-20, 3.4e20, 1, 2, 4, 1e10])
+    hand_b = np.float32([3, 7, 3, 2, 5, 5, 1e-10, 1e10, 0.3, 0.7, 3, 3, 0.99999994, 1.0000001, 7e19, 1.1e-19, 1e-30, 1e30, 2 ** -100, 2 ** 100])
+    a = np.concatenate([hand_a, a]).astype(np.float32)
+    b = np.concatenate([hand_b, b]).astype(np.float32)
+    q2, _ = torch.ops.egr.debug_lean_arith(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    ok = np.isfinite(a / b) & ((np.abs(a / b) >= np.float32(2.0 ** -126)) | (a == 0))  # quotient normal (or exactly 0): the accepted domain
+    got = q2.cpu().numpy()
+    bad = np.flatnonzero(ok & (got.view(np.uint32) != (a / b).view(np.uint32)) & ~((got == 0) & (a / b == 0)))  # (the sign of a zero quotient is not kept: -0 / 5 gives +0)
+    assert bad.size == 0, [(float(a[i]), float(b[i]), float(got[i]), float((a / b)[i])) for i in bad[:8]]
+    # square roots of the positive operands
+    _, r = torch.ops.egr.debug_lean_arith(torch.from_numpy(np.abs(a)).cuda(), torch.from_numpy(np.abs(b)).cuda())
+    rr, want = r.cpu().numpy(), np.sqrt(np.abs(a))
+    okr = (np.abs(a) >= np.float32(2.0 ** -100)) | (a == 0)
+    badr = np.flatnonzero(okr & (rr.view(np.uint32) != want.view(np.uint32)))
+    assert badr.size == 0, [(float(a[i]), float(rr[i]), float(want[i])) for i in badr[:8]]
+    # outside the domain (documented): b = 0 and b = inf give NaN where IEEE gives inf / 0 - never a finite wrong value
+    ea, eb = np.float32([1, 1, 0, np.inf]), np.float32([0, np.inf, 0, 2])
+    eq, _ = torch.ops.egr.debug_lean_arith(torch.from_numpy(ea).cuda(), torch.from_numpy(eb).cuda())
+    eq = eq.cpu().numpy()
+    report("lean_arith_outside_the_domain", one_over_zero=float(eq[0]), one_over_inf=float(eq[1]), zero_over_zero=float(eq[2]), inf_over_two=float(eq[3]))
+    assert all((not np.isfinite(x)) or x == 0.0 for x in eq), eq
