@@ -27,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-ROUND = "r5"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
+ROUND = "r6"  # profiles/<ROUND>/pmc_summary.json holds this round's rocprofv3 --pmc passes of this command (tools/profile.sh), one entry per workload
 
 
 def parse():
@@ -286,7 +286,7 @@ def main():
             # as profiles/<round>/pmc_summary.json, keyed by workload. bench.py cannot run the profiler around itself.
             pmc, pmc_round = {}, ROUND
             try:
-                pmc_round = next((r for r in (ROUND, "r4") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_summary.json"))), ROUND)  # (this round's passes once they are committed; the traffic source names the round)
+                pmc_round = next((r for r in (ROUND, "r5") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_summary.json"))), ROUND)  # (this round's passes once they are committed; the traffic source names the round)
                 pj = os.path.join(ROOT, "profiles", pmc_round, "pmc_summary.json")
                 if os.path.exists(pj) and world == 1 and a.emulate_world <= 1 and N == (100_000 if a.config == "B" else 1_000_000) and (W, H) == (1920, 1080):
                     pmc = json.load(open(pj)).get(f"{a.config}_{variant}", {})
