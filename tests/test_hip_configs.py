@@ -671,3 +671,31 @@ def test_caller_mirror_shoots_the_reference_cameras_rays(ren, syn):
         assert m.get_counters()[11] == 0
         del rt
     report("reference_camera_rays", worst_direction_error=f"{worst:.1e}", cameras=int(z["num_cases"]))
+
+
+def test_camera_and_target_uploads_follow_the_references_copy_semantics(ren, syn):
+    """`set_camera` / `set_targets_chw` replace the caller's `copy_` calls (gaussian_raytracer.py:94-137): like those they take tensors of any device, and a
+    target of another shape than [C, H, W] raises instead of being reinterpreted (a [H, W, C] image has the same number of elements)."""
+    W, H = 40, 24
+    g = syn.make_scene(300, "trained", seed=2)
+    cam = syn.default_camera()
+    tg = syn.make_targets(W, H)
+    rt = ren.GaussianRaytracer(ren.GaussianParams(g), W, H, ppll_forward_size=4_000_000, ppll_backward_size=4_000_000)
+    m = rt.cuda_module
+    chw = {k: torch.tensor(v).moveaxis(-1, 0).contiguous() for k, v in tg.items()}  # CPU tensors
+    m.set_targets_chw(chw["diffuse"], chw["specular"], chw["depth"], chw["normal"], chw["roughness"], chw["f0"])
+    fb = m.get_framebuffer()
+    assert torch.equal(fb.target_diffuse.cpu().reshape(H, W, 3), torch.tensor(tg["diffuse"]).reshape(H, W, 3))
+    with pytest.raises(RuntimeError):
+        m.set_targets_chw(torch.tensor(tg["diffuse"]).cuda(), None, None, None, None, None)  # [H, W, 3]: the reference's copy_(moveaxis) raises too
+    c = cam_obj(ren, cam)
+    m.get_config().jitter_primary_rays.fill_(False)
+    imgs = []
+    for R, centre in ((c.R.cpu(), c.camera_center.cpu()), (c.R, c.camera_center)):  # CPU tensors, then CUDA tensors: the same pose, the same image
+        m.set_camera(R, centre, float(c.FoVy), 0.01, 999.9)
+        m.update_bvh(False)
+        m.get_metadata().total_num_calls.zero_()  # (the same bounce samples for both launches)
+        with torch.no_grad():
+            m.raytrace()
+        imgs.append(fb.output_final.clone())
+    assert torch.equal(imgs[0], imgs[1]) and float(imgs[0].abs().sum()) > 0

@@ -206,3 +206,25 @@ def test_two_rank_partition_plus_allreduce_equals_single_rank(tmp_path, orc):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29517", str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=280)
     assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_all_reduce_launch_delta_folds_and_signals_consumed():
+    """The exchange step folds the per-launch buffer into the persistent one and - given the Raytracer - tells the library that the buffer is consumed,
+    so that the fold and the signal cannot be separated (without the signal the next launch ADDS to already rank-summed values). No process group here:
+    the collective is a no-op, the fold and the signal are not."""
+    import torch
+
+    par = importlib.import_module(PKG + ".parallel")
+
+    class FakeRaytracer:
+        consumed = 0
+
+        def grad_delta_consumed(self):
+            self.consumed += 1
+
+    flat, delta = torch.arange(8, dtype=torch.float32), torch.ones(8)
+    m = FakeRaytracer()
+    out = par.all_reduce_launch_delta(flat, delta, cuda_module=m)
+    assert out is flat and torch.equal(flat, torch.arange(8, dtype=torch.float32) + 1) and m.consumed == 1
+    par.all_reduce_launch_delta(flat, delta)  # a caller that signals itself
+    assert m.consumed == 1 and float(flat[0]) == 2.0
