@@ -120,6 +120,7 @@ enum ControlWord : int {
     CW_RESET_END = 28,  // words [0, CW_RESET_END) are zeroed by every launch
     CW_LIFE_RAYS = 28,  // lifetime totals (since egr_create / egr_reset_lifetime_counters), 64-bit
     CW_LIFE_LAUNCHES = 30,
+
     CW_DBG = 32,        // optional traversal statistics (EGR_TRAVERSAL_STATS builds): 8 x 64-bit
     CW_DBG2 = 48,       // per-phase s_memtime sums: [primary traversal, primary composite, bounce traversal, bounce composite]
     CW_DBG3 = 112,      // per forward step: min / max wave exit time (s_memrealtime)

@@ -87,8 +87,12 @@ EGR_DI void add64(uint32_t *ctrl, int word, uint32_t x) {
 }
 
 // T4: primary ray (core/camera.h:17-36). Draw order: jitter.x then jitter.y.
-EGR_DI f3 primary_direction(const DeviceView &v, int ix, int iy, bool jitter, uint32_t &seed) {
-    float view_size = tanf(*v.cam.vertical_fov_radians / 2.0f);
+// `view_size` = tanf(vertical_fov / 2) (core/camera.h:21), a launch constant that the compiler cannot hoist out of a task loop (a ~ 150-instruction range
+// reduction of a value read through a pointer). The BACKWARD chain evaluates it once in front of its task loop (-1.2 %: 2.37-2.39 against 2.40-2.41 ms, two
+// interleaved same-box pairs); the forward chain keeps it per tile: held across its task loop the value costs two more spilled VGPRs and 2 % (2.94-2.99 against
+// 2.89-2.90 ms), and read per tile from a word the prologue wrote it measures the same as the tanf (2.85-2.87 against 2.84-2.86 ms) - as long as that word sits on a
+// cache line of its own: on the line of the arena's bump counter the one load per tile took the chain from 2.9 to 4.5 ms.
+EGR_DI f3 primary_direction(const DeviceView &v, int ix, int iy, bool jitter, uint32_t &seed, const float view_size) {
     float aspect_ratio = (float)v.width / (float)v.height;
     float fx = (float)ix, fy = (float)iy;
     if (jitter) {
@@ -1120,6 +1124,7 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
     const float exp_power = *v.cfg.exp_power;
     const float eps_scale_grad = *v.cfg.eps_scale_grad;
     const int num_bounces = min(*v.cfg.num_bounces, EGR_MAX_BOUNCES);
+    const float view_size = tanf(*v.cam.vertical_fov_radians / 2.0f); // (primary_direction)
     uint32_t cur_q = blockIdx.x & 7u;
     uint32_t records = 0u; // 64-B gradient records this wave sent: bounce hits, primary hits without a table slot (two each), flushed table slots (two each) (egr_counters::bucket_records)
 
