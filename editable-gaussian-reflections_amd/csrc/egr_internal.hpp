@@ -18,7 +18,10 @@
 #define EGR_EMPTY_SLOT 0xFFFFFFFFu // unused child slot (checked before the leaf flag)
 #define EGR_WIDTH 8                // children per wide node: 8 x 16 B = one 128-B cache line
 #define EGR_MAX_STRANDS 4
-#define EGR_QUEUE_WORDS 16u          // task queue heads per strand: 2 kernels (forward chain, backward chain) x 8 XCD heads
+#ifndef EGR_QUEUE_STRIDE
+#define EGR_QUEUE_STRIDE 32u         // words between two task queue heads: every head on a 128-B line of its own (eight heads on ONE line = eight queues behind one atomic unit)
+#endif
+#define EGR_QUEUE_WORDS (16u * EGR_QUEUE_STRIDE) // task queue heads per strand: 2 kernels (forward chain, backward chain) x 8 XCD heads
 #define EGR_GSTK 232               // x 64 = entries of a resident wave's global spill column for its (ray, node) pair stack (the first EGR_PSTK live in LDS)
 #define EGR_EXT_BLOCK 16384u // entries of one candidate-list extension block
 #define EGR_EXT_NONE 0xFFFFFFFFu

@@ -63,7 +63,7 @@ EGR_DI uint32_t wave_next_task(uint32_t *heads, uint32_t num_tasks, uint32_t &cu
         const uint32_t beg = q * chunk, end = min(beg + chunk, num_tasks);
         if (beg >= end) continue;
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(heads + q, 1u);
+        if (lane == 0) t = atomicAdd(heads + q * EGR_QUEUE_STRIDE, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (beg + t < end) {
             cur_q = q;
@@ -1129,7 +1129,7 @@ template <int TEAM> __global__ void __launch_bounds__(EGR_WAVE * TEAM) __attribu
     uint32_t records = 0u; // 64-B gradient records this wave sent: bounce hits, primary hits without a table slot (two each), flushed table slots (two each) (egr_counters::bucket_records)
 
     for (;;) {
-        const uint32_t tq = wave_next_task(v.queues + 8, v.task_count, cur_q, lane);
+        const uint32_t tq = wave_next_task(v.queues + 8 * EGR_QUEUE_STRIDE, v.task_count, cur_q, lane);
         if (tq == 0xFFFFFFFFu) break;
 #if defined(EGR_TASK_TIMES) && EGR_TASK_TIMES == 8 // diagnostic build: stamps of a task's BACKWARD chain in its first pixels (tools/bwd_times.py)
         const unsigned long long bw_t0 = __builtin_amdgcn_s_memrealtime();
