@@ -113,10 +113,11 @@ struct DeviceView { // everything a kernel needs, passed by value
 
 enum ControlWord : int {
     CW_ACCEPTED = 0,    // per-step 64-bit counters: accepted candidates = what the reference inserts into its forward list
-    CW_HIT_BUMP = 8,    // arena block bump allocator
+    CW_HIT_BUMP = 128,  // arena block bump allocator: a returning atomic on the path of every eighth compositing batch - ON A CACHE LINE OF ITS OWN (words 128 .. 159;
+                        // it used to be word 8, on the line every wave adds its twelve per-step counters to when it leaves the kernel)
     CW_STATUS = 9,
     CW_BUCKET_RECORDS = 7, // 64-B gradient records (wide adds) the backward chain sent to the gradient rows in this launch
-    CW_EXT_BUMP = 6,       // candidate-list extension blocks handed out in this launch
+    CW_EXT_BUMP = 160,     // candidate-list extension blocks handed out in this launch (its own line too: words 160 .. 191)
     CW_RAYS = 10,       // per-step 64-bit counters (two words each): rays[3], candidates[3], composited[3]
     CW_CAND = 16,
     CW_COMP = 22,
@@ -127,7 +128,7 @@ enum ControlWord : int {
     CW_DBG = 32,        // optional traversal statistics (EGR_TRAVERSAL_STATS builds): 8 x 64-bit
     CW_DBG2 = 48,       // per-phase s_memtime sums: [primary traversal, primary composite, bounce traversal, bounce composite]
     CW_DBG3 = 112,      // per forward step: min / max wave exit time (s_memrealtime)
-    CW_COUNT = 128
+    CW_COUNT = 192      // (words from CW_DBG on are zeroed by every launch's prologue)
 };
 
 struct KernelStamp {

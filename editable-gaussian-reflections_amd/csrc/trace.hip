@@ -685,6 +685,9 @@ __global__ void __launch_bounds__(256) k_live(DeviceView v, int grads) {
 // says nothing about its cost at the next (measured correlation -0.2 .. -0.07; round 1: 315 -> 364 Mrays/s).
 // CUBE = the exact-statistics build (egr_set_exact_stats): the tree bounds the reference's instance CUBES and every cube overlap
 // is counted, so num_traversed_per_pixel is the reference's number (see forward_task.inc); images are the same.
+#ifndef EGR_ARENA_CHUNK
+#define EGR_ARENA_CHUNK 8 // hit-arena blocks a wave takes from the bump counter at a time (up to CHUNK - 1 blocks per resident wave stay unused: 29 k of the >= 469 k blocks of the reference's default capacity)
+#endif
 #ifndef EGR_FWD_WAVES
 #define EGR_FWD_WAVES 4 // waves per SIMD the forward chain is built for (register budget 512 / EGR_FWD_WAVES)
 #endif
@@ -695,6 +698,7 @@ template <bool GRADS, bool CUBE, int TEAM> __global__ void __launch_bounds__(EGR
     if (threadIdx.x < TEAM) team.box_count[threadIdx.x] = 0u, team.busy[threadIdx.x] = 0u;
     __syncthreads(); // the kernel's only workgroup barrier: from here on the waves of a team run independently
     uint32_t cur_q = blockIdx.x & 7u;
+    uint32_t arena_next = 0u, arena_end = 0u; // this wave's run of hit-arena blocks (forward_task.inc)
 
     for (;;) {
         const uint32_t tq = slot < v.num_slots ? wave_next_task(v.queues, v.task_count, cur_q, lane) : 0xFFFFFFFFu;

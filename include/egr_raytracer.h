@@ -108,7 +108,8 @@ typedef struct egr_counters {
     uint32_t bucket_records;             /* 64-B gradient records (16-lane atomic adds) the backward chain sent to the gradient rows in this launch */
     uint64_t device_bytes;               /* device memory this context holds right now (scratch, arena, ray state, tree, records);
                                           * the caller's tensors (parameters, gradients, framebuffer) are not included          */
-    uint32_t arena_blocks_used, arena_blocks_cap; /* composited-hit arena (backward capacity): 9-KB blocks the last grad launch took / holds */
+    uint32_t arena_blocks_used, arena_blocks_cap; /* composited-hit arena (backward capacity): 9-KB blocks the last grad launch took (waves take them in runs of 8:
+                                                   * up to 7 per resident wave are taken and not written) / holds */
     uint32_t ext_blocks_used, ext_blocks_cap;     /* candidate-list extension blocks (forward capacity) the last launch took / holds         */
     uint64_t accepted[EGR_NUM_STEPS];    /* accepted candidates per step = entries the reference inserts into its forward list
                                           * (shaders.cu:74; its counter runs on over the three steps, so their SUM must stay below
