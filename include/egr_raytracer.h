@@ -195,7 +195,9 @@ int egr_tile_owner(int width, int height, int world_size, int tile_index);
  * fold: multi-view accumulation, a caller that raised between launch and fold - ADDS to it like the default path, so no launch's
  * gradients or total_weight are ever dropped. */
 int egr_set_grad_overwrite(egr_context *ctx, int enable);
-/* The caller has folded the per-launch buffer into its persistent gradients (after the all-reduce): the next grad launch stores again. */
+/* The caller has folded the per-launch buffer into its persistent gradients (after the all-reduce): the next grad launch stores again.
+ * REQUIRED after every fold (changed in library version 0.6: until then every launch stored): a host that all-reduces the buffer in place and
+ * never calls this has every later launch ADD to the already rank-summed values, and the next reduce sums those again. */
 int egr_grad_delta_consumed(egr_context *ctx);
 
 /* Exact statistics (not in the reference). By default the tree bounds each Gaussian's ELLIPSOID and the walk only has to find the
